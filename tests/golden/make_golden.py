@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the REAL reference (pyAudioDspTools @ /root/reference).
+
+Run in the build container only (the reference never travels to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/make_golden.py
+
+Writes small ``.npz`` fixtures next to this script.  Inputs are regenerated from seeds by the
+tests (``numpy.random.default_rng(seed).uniform(-1, 1, n).astype(float32)``), so only outputs,
+design kernels and a few spot values are stored.  Nothing from the reference's source text is
+stored - only numbers it produced.
+"""
+import hashlib
+import io
+import os
+import sys
+import contextlib
+
+import numpy as np
+
+REF = os.environ.get("ADSP_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+with contextlib.redirect_stdout(io.StringIO()):  # the reference prints a cupy info line on import
+    import pyAudioDspTools as ref  # noqa: E402
+
+
+def stream(seed, n_total):
+    return np.random.default_rng(seed).uniform(-1, 1, n_total).astype(np.float32)
+
+
+def run_device(dev, x, n):
+    return np.concatenate([dev.apply(x[i * n:(i + 1) * n]) for i in range(len(x) // n)])
+
+
+def taps_of(spectrum, taps):
+    return np.fft.ifft(spectrum).real[:taps].copy()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}.npz  {os.path.getsize(path)} bytes")
+
+
+def main():
+    meta = {"numpy": np.__version__}
+
+    # ---- design kernels -------------------------------------------------------------
+    design = {}
+    for fs, n, fc in [(44100, 4096, 800), (44100, 512, 200), (96000, 8192, 800), (44100, 4096, 160), (48000, 1024, 50)]:
+        ref.config.initialize(fs, n)
+        dev = ref.CreateLowCutFilter(fc)
+        design[f"lowcut_{fs}_{n}_{fc}"] = taps_of(dev.sinc_filter, dev.filter_length)
+    for fs, n, fc in [(44100, 4096, 8000), (44100, 512, 8000), (96000, 8192, 8000), (48000, 1024, 20000)]:
+        ref.config.initialize(fs, n)
+        dev = ref.CreateHighCutFilter(fc)
+        design[f"highcut_{fs}_{n}_{fc}"] = taps_of(dev.sinc_filter, dev.filter_length)
+    for fs, n, p in [(44100, 512, (100, 2, 700, -4, 8000, 5)), (44100, 4096, (100, 2, 700, -4, 8000, 5)),
+                     (96000, 8192, (100, 2, 700, -4, 8000, 5)), (48000, 1024, (250, -6, 1500, 3, 6000, -2.5))]:
+        ref.config.initialize(fs, n)
+        dev = ref.CreateEQ3BandFFT(*p)
+        tag = f"eq_{fs}_{n}_" + "_".join(str(v) for v in p)
+        design[tag + "_highshelf"] = taps_of(dev.sinc_filter_highshelf, dev.filter_length)
+        design[tag + "_lowshelf"] = taps_of(dev.sinc_filter_lowshelf, dev.filter_length)
+        design[tag + "_mid_lowpass"] = taps_of(dev.sinc_filter_mid_lowpass, dev.filter_length)
+        design[tag + "_mid_highpass"] = taps_of(dev.sinc_filter_mid_highpass, dev.filter_length)
+    # default-argument constructors (EffectFFTFilter.py:18 / :91)
+    ref.config.initialize(44100, 512)
+    design["highcut_default_44100_512"] = taps_of(ref.CreateHighCutFilter().sinc_filter, 255)
+    design["lowcut_default_44100_512"] = taps_of(ref.CreateLowCutFilter().sinc_filter, 255)
+    # spectrum spot values quoted in SURVEY 8c
+    ref.config.initialize(44100, 4096)
+    hc = ref.CreateHighCutFilter(8000)
+    lc = ref.CreateLowCutFilter(800)
+    design["spot_B_H01"] = np.array([hc.sinc_filter[0], hc.sinc_filter[1]])
+    design["spot_A_H0_Hnyq"] = np.array([lc.sinc_filter[0], lc.sinc_filter[3 * 4096 // 2]])
+    save("design", **design)
+
+    # ---- KAT streams A-D (seed 1234, 6 chunks) ----------------------------------------
+    kat = {}
+    ref.config.initialize(44100, 4096)
+    kat["A"] = run_device(ref.CreateLowCutFilter(800), stream(1234, 6 * 4096), 4096)
+    kat["B"] = run_device(ref.CreateHighCutFilter(8000), stream(1234, 6 * 4096), 4096)
+    ref.config.initialize(44100, 512)
+    kat["C"] = run_device(ref.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), stream(1234, 6 * 512), 512)
+    kat["D"] = run_device(ref.CreateLowCutFilter(200), stream(1234, 6 * 512), 512)
+    # extra shapes: EQ at 4096, filters at 8192/96k, N=1024/48k, N=64 (smallest supported)
+    ref.config.initialize(44100, 4096)
+    kat["EQ4096"] = run_device(ref.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), stream(77, 5 * 4096), 4096)
+    ref.config.initialize(96000, 8192)
+    kat["LC8192"] = run_device(ref.CreateLowCutFilter(800), stream(78, 4 * 8192), 8192)
+    kat["EQ8192"] = run_device(ref.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), stream(79, 4 * 8192), 8192)
+    ref.config.initialize(48000, 1024)
+    kat["HC1024"] = run_device(ref.CreateHighCutFilter(20000), stream(80, 7 * 1024), 1024)
+    kat["EQ1024"] = run_device(ref.CreateEQ3BandFFT(250, -6, 1500, 3, 6000, -2.5), stream(81, 7 * 1024), 1024)
+    ref.config.initialize(44100, 2048)
+    kat["LC2048"] = run_device(ref.CreateLowCutFilter(160), stream(82, 5 * 2048), 2048)
+    ref.config.initialize(44100, 256)
+    kat["HC256"] = run_device(ref.CreateHighCutFilter(3000), stream(83, 9 * 256), 256)
+    ref.config.initialize(44100, 128)
+    kat["EQ128"] = run_device(ref.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), stream(84, 9 * 128), 128)
+    ref.config.initialize(44100, 64)
+    kat["LC64"] = run_device(ref.CreateLowCutFilter(2000), stream(85, 11 * 64), 64)
+    for k in "ABCD":
+        meta["sha_" + k] = hashlib.sha256(kat[k].tobytes()).hexdigest()[:12]
+    save("kat_streams", **kat)
+
+    # ---- E: chain LowCut(800) -> EQ3 -> HighCut(8000), 96 kHz, N=8192, 12 chunks ------------
+    ref.config.initialize(96000, 8192)
+    a, b, c = ref.CreateLowCutFilter(800), ref.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), ref.CreateHighCutFilter(8000)
+    x = stream(4321, 12 * 8192)
+    y = np.concatenate([c.apply(b.apply(a.apply(x[i * 8192:(i + 1) * 8192]))) for i in range(12)])
+    save("kat_chain", E=y)
+
+    # ---- F: Example1 plumbing on the reference's own 16-bit mono WAV -------------------------
+    ref.config.initialize(44100, 4096)
+    with contextlib.redirect_stdout(io.StringIO()):
+        full = ref.Utility.MonoWavToNumpyFloat(os.path.join(REF, "TestFile16BitMono.wav"))
+    chunks = ref.MakeChunks(full)
+    dev = ref.CreateLowCutFilter(800)
+    outs = [dev.apply(ch) for ch in chunks]
+    merged = ref.CombineChunks(outs)
+    meta["example1_len_in"] = int(len(full))
+    meta["example1_n_chunks"] = int(len(chunks))
+    meta["example1_sha16"] = hashlib.sha256(merged.tobytes()).hexdigest()[:16]
+    first8_in = np.round(np.concatenate(chunks[:8]) * 32768).astype(np.int16)  # exact: samples are int16/32768
+    assert np.array_equal(first8_in.astype(np.float32) / 32768, np.concatenate(chunks[:8]))
+    save("kat_example1", pcm16_first8=first8_in, out_first8=np.concatenate(outs[:8]),
+         out_len=np.array([len(merged)]))
+
+    # ---- G: edge inputs, N=512 for each device -----------------------------------------------
+    n = 512
+    edge_inputs = {
+        "zeros": np.zeros(5 * n, np.float32),
+        "imp0": np.eye(1, 5 * n, 0, dtype=np.float32)[0],
+        "impNm1": np.eye(1, 5 * n, n - 1, dtype=np.float32)[0],
+        "impN": np.eye(1, 5 * n, n, dtype=np.float32)[0],
+        "dc": np.ones(5 * n, np.float32),
+        "square": np.where((np.arange(5 * n) // 37) % 2 == 0, 1.0, -1.0).astype(np.float32),
+    }
+    edge = {}
+    for name, x in edge_inputs.items():
+        ref.config.initialize(44100, n)
+        edge["lowcut_" + name] = run_device(ref.CreateLowCutFilter(200), x, n)
+        edge["highcut_" + name] = run_device(ref.CreateHighCutFilter(8000), x, n)
+        edge["eq_" + name] = run_device(ref.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), x, n)
+    # input-type behaviour: float64 chunks and python lists are accepted (concatenate axis=None)
+    ref.config.initialize(44100, n)
+    x64 = np.random.default_rng(5).uniform(-1, 1, 4 * n)
+    edge["lowcut_f64in"] = run_device(ref.CreateLowCutFilter(200), x64, n)
+    dev = ref.CreateHighCutFilter(8000)
+    edge["highcut_listin"] = np.concatenate([dev.apply(list(x64[i * n:(i + 1) * n])) for i in range(4)])
+    save("kat_edges", **edge)
+
+    with open(os.path.join(HERE, "META.txt"), "w") as fh:
+        for k in sorted(meta):
+            fh.write(f"{k} = {meta[k]}\n")
+    print(meta)
+
+
+if __name__ == "__main__":
+    main()
