@@ -1,0 +1,143 @@
+/*
+ * adsp.h - C ABI of the MI355X-native batched FFT filter / FFT-EQ engine (libadsp.so).
+ *
+ * This is the drop-in boundary of the hot path.  The reference (ArjaanAuinger/pyaudiodsptools) is
+ * pure Python and has no FFI of its own; the entry points below are what a Python binding for
+ *
+ *     CreateHighCutFilter.apply / CreateLowCutFilter.apply   pyAudioDspTools/EffectFFTFilter.py:49-75, :125-151
+ *     CreateEQ3BandFFT.apply                                  pyAudioDspTools/EffectEQ3BandFFT.py:156-211
+ *
+ * binds (see INTEGRATION.md for the ctypes stub).  The reference's apply() is, exactly, a
+ * streaming FIR with one chunk of latency; this library computes the same
+ * stream for C independent mono channels at once with an overlap-save real FFT executed by
+ * hand-written HIP kernels for gfx950.  The engine is filter-agnostic: the host designs the FIR
+ * (float64), hands over its spectrum, and says where in the transform window the kept samples
+ * live.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative adsp_status on failure; the message is
+ *     available from adsp_last_error() (thread-local).  No exception crosses this ABI.
+ *   - plain pointers and sizes only; no torch / numpy types.
+ *   - one host thread per engine at a time (the reference's devices are not thread-safe either,
+ *     EffectFFTFilter.py:63-65); distinct engines are independent.
+ *   - the library owns all device memory it allocates; "d_" pointers are caller-owned device
+ *     memory, all others are host memory.
+ *   - batch layout everywhere: [step][channel][sample] row-major float32, i.e. the chunk of
+ *     channel c at step k starts at ((k * n_channels) + c) * chunk_size.
+ */
+#ifndef ADSP_H
+#define ADSP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define ADSP_API __attribute__((visibility("default")))
+#else
+#define ADSP_API
+#endif
+
+#define ADSP_ABI_VERSION 1
+#define ADSP_MAX_HISTORY 8
+
+typedef enum adsp_status {
+    ADSP_OK = 0,
+    ADSP_ERR_ARG = -1,        /* bad argument / unsupported geometry */
+    ADSP_ERR_HIP = -2,        /* a HIP runtime call failed */
+    ADSP_ERR_STATE = -3,      /* call sequence error (e.g. apply before set_spectrum) */
+    ADSP_ERR_NO_DEVICE = -4   /* no usable GPU */
+} adsp_status;
+
+typedef struct adsp_engine adsp_engine; /* opaque */
+
+/*
+ * Geometry of one streaming FIR engine.
+ *
+ * For an output block that starts at output-time o (o = 0 is the first sample returned by the
+ * first apply() after reset), the kernel transforms the fft_size input samples starting at
+ * input-time o - lookback (input-time 0 is the first sample ever fed; earlier samples are the
+ * zero history of EffectFFTFilter.py:40-42), multiplies by the spectrum and keeps block_outputs
+ * samples starting at circular index out_offset of the inverse transform.
+ *
+ * Single reference device with chunk N (L = N/2-1 taps, d = (L-1)/2):
+ *   low/high cut : fft_size 2N, history_chunks 2, lookback N + N/4, out_offset N/2  (kernel delayed by 1 tap)
+ *   3-band EQ    : fft_size 2N, history_chunks 2, lookback 2N - N/4, out_offset N  (kernel delayed by 1 tap)
+ */
+typedef struct adsp_config {
+    int device_id;       /* HIP device ordinal */
+    int chunk_size;      /* N: samples per channel per step; power of two, 64..8192 */
+    int n_channels;      /* C: independent mono channels held by this engine */
+    int fft_size;        /* F: real transform length, power of two, 2N or 4N, F/2 in 64..16384 */
+    int history_chunks;  /* past chunks the window can reach (1..ADSP_MAX_HISTORY) */
+    int lookback;        /* see above; 0 < lookback <= history_chunks*N, multiple of 4N/.. (checked) */
+    int out_offset;      /* see above */
+    int ring_slots;      /* input ring length for the zero-copy streaming path; 0 = history_chunks+1 */
+} adsp_config;
+
+/* ABI version (ADSP_ABI_VERSION of the built library). */
+ADSP_API int adsp_version(void);
+
+/* Thread-local description of the last failure on this thread ("" if none). */
+ADSP_API const char* adsp_last_error(void);
+
+/* Number of visible GPUs (0 and ADSP_ERR_NO_DEVICE when there is none). */
+ADSP_API int adsp_device_count(int* count);
+
+/* 0 if a kernel plan exists for this (chunk_size, fft_size), ADSP_ERR_ARG otherwise.  Needs no GPU. */
+ADSP_API int adsp_plan_supported(int chunk_size, int fft_size);
+
+/* Describe the plan chosen for (chunk_size, fft_size): complex points M, points per thread,
+ * threads per transform, channels per workgroup, LDS bytes per workgroup.  Needs no GPU. */
+ADSP_API int adsp_plan_describe(int chunk_size, int fft_size, int* complex_points, int* points_per_thread,
+                       int* threads_per_transform, int* channels_per_workgroup, int* lds_bytes);
+
+/* Allocate an engine: zeroed input ring [ring_slots][C][N], twiddle tables.  Replaces the
+ * reference constructors' state setup (EffectFFTFilter.py:39-42; EffectEQ3BandFFT.py:147-152). */
+ADSP_API int adsp_create(const adsp_config* cfg, adsp_engine** out_engine);
+ADSP_API int adsp_destroy(adsp_engine* engine);
+
+/* Upload the filter spectrum: n_bins = F/2+1 interleaved (re,im) float32 values of rfft(kernel, F),
+ * computed by the host in float64.  Replaces self.sinc_filter (EffectFFTFilter.py:45-47) and the
+ * four EQ spectra + per-call recombination (EffectEQ3BandFFT.py:88-143, :182-188).  May be called
+ * again at any time to change the filter (takes effect for the next apply). */
+ADSP_API int adsp_set_spectrum(adsp_engine* engine, const float* spectrum_interleaved, int n_bins);
+
+/* Same, from device memory (e.g. after an RCCL broadcast). */
+ADSP_API int adsp_set_spectrum_device(adsp_engine* engine, const float* d_spectrum_interleaved, int n_bins, void* stream);
+
+/* Samples kept per transform in multi-step launches (apply_device with n_steps > 1).  Default is
+ * chunk_size; any multiple of 2*threads_per_transform up to fft_size - out_offset is valid and
+ * larger is cheaper (1.5 N for the cut filters at F = 2N). */
+ADSP_API int adsp_set_block_outputs(adsp_engine* engine, int block_outputs);
+
+/* Forget all history (a fresh reference device). */
+ADSP_API int adsp_reset(adsp_engine* engine);
+
+/* The reference's apply() on host buffers, batched: in/out are [n_steps][C][N] float32 host arrays
+ * (in is only read, out is fully overwritten).  H2D -> kernel -> D2H, synchronous on return. */
+ADSP_API int adsp_apply_host(adsp_engine* engine, const float* in, float* out, int n_steps);
+
+/* The measured path: device-resident [n_steps][C][N] batches, asynchronous on `stream`
+ * (a hipStream_t passed as void*; NULL = the default stream).  d_in must stay unmodified until the
+ * work on `stream` has finished.  History is carried inside the engine between calls. */
+ADSP_API int adsp_apply_device(adsp_engine* engine, const float* d_in, float* d_out, int n_steps, void* stream);
+
+/* Zero-copy streaming: the producer (H2D copy, decoder, generator kernel) writes the next chunk
+ * batch [C][N] straight into the ring slot returned by adsp_ring_acquire, then adsp_apply_ring
+ * filters it.  No state copy, 1.25-1.75 N reads + N writes per channel per step. */
+ADSP_API int adsp_ring_acquire(adsp_engine* engine, float** d_slot);
+ADSP_API int adsp_apply_ring(adsp_engine* engine, float* d_out, void* stream);
+
+/* Test hooks: the engine's history as [history_chunks][C][N] host floats, oldest first
+ * (the reference's float32_array_input_3/_2). */
+ADSP_API int adsp_get_state(adsp_engine* engine, float* host_history);
+ADSP_API int adsp_set_state(adsp_engine* engine, const float* host_history);
+
+/* Block until everything this engine enqueued on `stream` is done. */
+ADSP_API int adsp_synchronize(adsp_engine* engine, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADSP_H */

@@ -1,0 +1,20 @@
+"""pyaudiodsptools_amd - MI355X-native drop-in for pyAudioDspTools' FFT filter / FFT-EQ devices.
+
+    import pyaudiodsptools_amd as pyAudioDspTools
+    pyAudioDspTools.config.initialize(44100, 4096)
+    dev = pyAudioDspTools.CreateLowCutFilter(800)
+    out_chunk = dev.apply(in_chunk)
+
+Only the FFT-filter hot path of the reference is implemented; the arithmetic
+runs in hand-written HIP kernels behind the C ABI of include/adsp.h.  Importing the package does
+not need a GPU; creating a device does.
+"""
+from . import config
+from .design import FirStream
+from .devices import (CreateEQ3BandFFT, CreateEQ3BandFFTGPU, CreateHighCutFilter, CreateHighCutFilterGPU,
+                      CreateLowCutFilter, CreateLowCutFilterGPU, fuse)
+from .engine import FirEngine
+
+__all__ = ["config", "CreateHighCutFilter", "CreateLowCutFilter", "CreateEQ3BandFFT", "CreateHighCutFilterGPU",
+           "CreateLowCutFilterGPU", "CreateEQ3BandFFTGPU", "FirEngine", "FirStream", "fuse"]
+__version__ = "0.1.0"

@@ -1,0 +1,99 @@
+"""ctypes binding of libadsp.so (include/adsp.h).  Fails loudly when the HIP library is missing:
+there is no CPU fallback anywhere in this package."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libadsp.so")
+
+ADSP_ABI_VERSION = 1
+ADSP_MAX_HISTORY = 8
+ADSP_OK, ADSP_ERR_ARG, ADSP_ERR_HIP, ADSP_ERR_STATE, ADSP_ERR_NO_DEVICE = 0, -1, -2, -3, -4
+
+
+class AdspError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libadsp error {code}: {message}")
+        self.code = code
+
+
+class AdspConfig(ctypes.Structure):
+    _fields_ = [
+        ("device_id", ctypes.c_int),
+        ("chunk_size", ctypes.c_int),
+        ("n_channels", ctypes.c_int),
+        ("fft_size", ctypes.c_int),
+        ("history_chunks", ctypes.c_int),
+        ("lookback", ctypes.c_int),
+        ("out_offset", ctypes.c_int),
+        ("ring_slots", ctypes.c_int),
+    ]
+
+
+_c_int_p = ctypes.POINTER(ctypes.c_int)
+_c_float_p = ctypes.POINTER(ctypes.c_float)
+_engine_p = ctypes.c_void_p
+
+# name -> (restype, argtypes); every symbol include/adsp.h declares
+SIGNATURES = {
+    "adsp_version": (ctypes.c_int, []),
+    "adsp_last_error": (ctypes.c_char_p, []),
+    "adsp_device_count": (ctypes.c_int, [_c_int_p]),
+    "adsp_plan_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "adsp_plan_describe": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _c_int_p, _c_int_p, _c_int_p, _c_int_p, _c_int_p]),
+    "adsp_create": (ctypes.c_int, [ctypes.POINTER(AdspConfig), ctypes.POINTER(_engine_p)]),
+    "adsp_destroy": (ctypes.c_int, [_engine_p]),
+    "adsp_set_spectrum": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_int]),
+    "adsp_set_spectrum_device": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "adsp_set_block_outputs": (ctypes.c_int, [_engine_p, ctypes.c_int]),
+    "adsp_reset": (ctypes.c_int, [_engine_p]),
+    "adsp_apply_host": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    "adsp_apply_device": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "adsp_ring_acquire": (ctypes.c_int, [_engine_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "adsp_apply_ring": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "adsp_get_state": (ctypes.c_int, [_engine_p, ctypes.c_void_p]),
+    "adsp_set_state": (ctypes.c_int, [_engine_p, ctypes.c_void_p]),
+    "adsp_synchronize": (ctypes.c_int, [_engine_p, ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libadsp.so (once) and declare every prototype.  Raises ImportError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C pyaudiodsptools_amd/csrc`. "
+            "pyaudiodsptools_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.adsp_version() != ADSP_ABI_VERSION:
+        raise ImportError(f"libadsp ABI {lib.adsp_version()} != binding {ADSP_ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        msg = load().adsp_last_error()
+        raise AdspError(code, msg.decode("utf-8", "replace") if msg else "")
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    rc = load().adsp_device_count(ctypes.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def plan_describe(chunk_size, fft_size):
+    vals = [ctypes.c_int(0) for _ in range(5)]
+    check(load().adsp_plan_describe(chunk_size, fft_size, *[ctypes.byref(v) for v in vals]))
+    keys = ("complex_points", "points_per_thread", "threads_per_transform", "channels_per_workgroup", "lds_bytes")
+    return dict(zip(keys, (v.value for v in vals)))

@@ -1,0 +1,475 @@
+// adsp_capi.hip - C ABI (include/adsp.h) over the fused overlap-save kernel.
+// Host logic only: plan registry, twiddle / spectrum-pair tables (float64 -> float32), the input
+// history ring, launches.  There is deliberately NO CPU fallback: without a GPU every compute
+// entry point fails with ADSP_ERR_NO_DEVICE / ADSP_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/adsp.h"
+#include "fftconv_kernel.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return fail(ADSP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// plan registry
+// ------------------------------------------------------------------------------------------
+struct PlanInfo {
+    int M, P, T, CPB, NP;
+    int rad[4];
+    int tw_total;
+    int lds_bytes;
+    hipError_t (*launch)(const adsp::KernelArgs&, int grid, hipStream_t);
+    hipError_t (*prepare)();
+};
+
+template <class PL, int CPB>
+hipError_t launch_impl(const adsp::KernelArgs& a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((adsp::fftconv_kernel<PL, CPB>), dim3(grid), dim3(PL::T * CPB), PL::M * CPB * sizeof(float2), s, a);
+    return hipGetLastError();
+}
+
+template <class PL, int CPB>
+hipError_t prepare_impl() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&adsp::fftconv_kernel<PL, CPB>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, PL::M * CPB * (int)sizeof(float2));
+}
+
+template <class PL, int CPB>
+constexpr PlanInfo make_plan() {
+    return PlanInfo{PL::M, PL::P, PL::T, CPB, PL::NP, {PL::fwd(0), PL::fwd(1), PL::fwd(2), PL::fwd(3)},
+                    PL::tw_total, PL::M * CPB * (int)sizeof(float2), &launch_impl<PL, CPB>, &prepare_impl<PL, CPB>};
+}
+
+using adsp::Plan;
+// M (complex points) -> plan.  Last forward radix is always P/2 (see fftconv_kernel.hpp).
+const PlanInfo kPlans[] = {
+    make_plan<Plan<64, 16, 2, 8, 8, 1, 1>, 16>(),
+    make_plan<Plan<128, 16, 2, 16, 8, 1, 1>, 8>(),
+    make_plan<Plan<256, 16, 3, 4, 8, 8, 1>, 4>(),
+    make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 2>(),
+    make_plan<Plan<1024, 16, 3, 16, 8, 8, 1>, 1>(),
+    make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1>(),
+    make_plan<Plan<4096, 32, 3, 16, 16, 16, 1>, 1>(),
+    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1>(),
+    make_plan<Plan<16384, 32, 4, 32, 2, 16, 16>, 1>(),
+};
+
+const PlanInfo* find_plan(int M) {
+    for (const PlanInfo& p : kPlans)
+        if (p.M == M) return &p;
+    return nullptr;
+}
+
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+int check_geometry(int N, int F, const PlanInfo** out) {
+    if (!is_pow2(N) || N < 64 || N > 8192) return fail(ADSP_ERR_ARG, "chunk_size %d: need a power of two in 64..8192", N);
+    if (F != 2 * N && F != 4 * N) return fail(ADSP_ERR_ARG, "fft_size %d: need 2*chunk_size or 4*chunk_size", F);
+    const PlanInfo* p = find_plan(F / 2);
+    if (!p) return fail(ADSP_ERR_ARG, "no kernel plan for %d complex points", F / 2);
+    if (out) *out = p;
+    return ADSP_OK;
+}
+
+// forward-sign twiddles for passes 1.. of the forward then the inverse radix order
+void build_twiddles(const PlanInfo& pl, std::vector<float2>& tw) {
+    tw.clear();
+    for (int dir = 0; dir < 2; ++dir) {
+        int S = 1;
+        for (int p = 0; p < pl.NP; ++p) {
+            const int R = dir == 0 ? pl.rad[p] : pl.rad[pl.NP - 1 - p];
+            if (p > 0) {
+                for (int q = 1; q < R; ++q)
+                    for (int jlo = 0; jlo < S; ++jlo) {
+                        const double ang = -2.0 * M_PI * (double)q * (double)jlo / ((double)R * (double)S);
+                        tw.push_back(make_float2((float)std::cos(ang), (float)std::sin(ang)));
+                    }
+            }
+            S *= R;
+        }
+    }
+}
+
+struct PairEntry {
+    float2 wc, g1, g2;
+};
+
+PairEntry pair_entry(const float* H, int M, int k) {
+    // wc = -i * exp(-i*pi*k/M);  g1 = H[k]/(4M);  g2 = conj(H[M-k])/(4M)
+    const double ang = M_PI * (double)k / (double)M;
+    const double sc = 1.0 / (4.0 * (double)M);
+    PairEntry e;
+    e.wc = make_float2((float)(-std::sin(ang)), (float)(-std::cos(ang)));
+    e.g1 = make_float2((float)(H[2 * k] * sc), (float)(H[2 * k + 1] * sc));
+    e.g2 = make_float2((float)(H[2 * (M - k)] * sc), (float)(-H[2 * (M - k) + 1] * sc));
+    return e;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+struct adsp_engine {
+    adsp_config cfg;
+    const PlanInfo* plan;
+    int M, logN, block_outputs;
+    float* ring;   // [ring_slots][C][N]
+    int ring_pos;  // slot of the most recent chunk
+    float2* tw;
+    float2* pair;
+    float2* pair0;
+    bool have_spectrum;
+    float* stage_in;
+    float* stage_out;
+    size_t stage_elems;
+    size_t plane() const { return (size_t)cfg.n_channels * (size_t)cfg.chunk_size; }
+};
+
+namespace {
+
+int set_device(const adsp_engine* e) {
+    HIP_TRY(hipSetDevice(e->cfg.device_id));
+    return ADSP_OK;
+}
+
+int upload_pairs(adsp_engine* e, const float* H, hipStream_t stream) {
+    const PlanInfo& pl = *e->plan;
+    const int M = e->M, T = pl.T, R = pl.P / 2;
+    std::vector<float2> tab((size_t)R * 3 * T, make_float2(0.f, 0.f));
+    for (int r = 0; r < R; ++r)
+        for (int tid = 1; tid < T; ++tid) {
+            const PairEntry pe = pair_entry(H, M, tid + 2 * T * r);
+            tab[(size_t)(r * 3 + 0) * T + tid] = pe.wc;
+            tab[(size_t)(r * 3 + 1) * T + tid] = pe.g1;
+            tab[(size_t)(r * 3 + 2) * T + tid] = pe.g2;
+        }
+    std::vector<float2> tab0((size_t)(R + 1) * 3);
+    auto put0 = [&](int idx, int k) {
+        const PairEntry pe = pair_entry(H, M, k);
+        tab0[idx * 3 + 0] = pe.wc;
+        tab0[idx * 3 + 1] = pe.g1;
+        tab0[idx * 3 + 2] = pe.g2;
+    };
+    put0(0, 0);
+    put0(1, M / 2);
+    for (int r = 1; r < R / 2; ++r) put0(2 + (r - 1), 2 * T * r);
+    for (int r = 0; r < R / 2; ++r) put0(2 + (R / 2 - 1) + r, T + 2 * T * r);
+    // synchronous copies from pageable memory: safe to free the vectors on return
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipMemcpy(e->pair, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->pair0, tab0.data(), tab0.size() * sizeof(float2), hipMemcpyHostToDevice));
+    e->have_spectrum = true;
+    return ADSP_OK;
+}
+
+int launch(adsp_engine* e, const float* d_in, float* d_out, int n_steps, hipStream_t stream) {
+    const adsp_config& c = e->cfg;
+    const PlanInfo& pl = *e->plan;
+    adsp::KernelArgs a;
+    a.ring = e->ring;
+    a.in = d_in;
+    a.out = d_out;
+    a.tw = e->tw;
+    a.pair = e->pair;
+    a.pair0 = e->pair0;
+    a.ring_pos = e->ring_pos;
+    a.ring_slots = c.ring_slots;
+    a.C = c.n_channels;
+    a.n_steps = n_steps;
+    a.logN = e->logN;
+    a.V = n_steps == 1 ? c.chunk_size : e->block_outputs;
+    const long long total = (long long)n_steps * c.chunk_size;
+    a.nblk = (int)((total + a.V - 1) / a.V);
+    a.lookback = c.lookback;
+    a.j0 = c.out_offset;
+    a.ncg = (c.n_channels + pl.CPB - 1) / pl.CPB;
+    const long long grid = (long long)((a.ncg + 7) / 8) * 8 * a.nblk;
+    if (grid > 0x7fffffffLL) return fail(ADSP_ERR_ARG, "launch too large (%lld workgroups)", grid);
+    HIP_TRY(pl.launch(a, (int)grid, stream));
+    return ADSP_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int adsp_version(void) { return ADSP_ABI_VERSION; }
+
+const char* adsp_last_error(void) { return g_last_error.c_str(); }
+
+int adsp_device_count(int* count) {
+    if (!count) return fail(ADSP_ERR_ARG, "count is NULL");
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess || n <= 0) {
+        *count = 0;
+        (void)hipGetLastError();
+        return fail(ADSP_ERR_NO_DEVICE, "no HIP device: %s", hipGetErrorString(err));
+    }
+    *count = n;
+    return ADSP_OK;
+}
+
+int adsp_plan_supported(int chunk_size, int fft_size) { return check_geometry(chunk_size, fft_size, nullptr); }
+
+int adsp_plan_describe(int chunk_size, int fft_size, int* complex_points, int* points_per_thread,
+                       int* threads_per_transform, int* channels_per_workgroup, int* lds_bytes) {
+    const PlanInfo* p = nullptr;
+    int rc = check_geometry(chunk_size, fft_size, &p);
+    if (rc) return rc;
+    if (complex_points) *complex_points = p->M;
+    if (points_per_thread) *points_per_thread = p->P;
+    if (threads_per_transform) *threads_per_transform = p->T;
+    if (channels_per_workgroup) *channels_per_workgroup = p->CPB;
+    if (lds_bytes) *lds_bytes = p->lds_bytes;
+    return ADSP_OK;
+}
+
+int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
+    if (!cfg || !out_engine) return fail(ADSP_ERR_ARG, "NULL argument");
+    *out_engine = nullptr;
+    const PlanInfo* pl = nullptr;
+    int rc = check_geometry(cfg->chunk_size, cfg->fft_size, &pl);
+    if (rc) return rc;
+    const int N = cfg->chunk_size, F = cfg->fft_size, T2 = 2 * pl->T;
+    if (cfg->n_channels <= 0) return fail(ADSP_ERR_ARG, "n_channels must be positive");
+    if (cfg->history_chunks < 1 || cfg->history_chunks > ADSP_MAX_HISTORY)
+        return fail(ADSP_ERR_ARG, "history_chunks %d out of range 1..%d", cfg->history_chunks, ADSP_MAX_HISTORY);
+    if (cfg->lookback <= 0 || cfg->lookback > cfg->history_chunks * N || cfg->lookback % T2)
+        return fail(ADSP_ERR_ARG, "lookback %d must be in (0, history_chunks*N] and a multiple of %d", cfg->lookback, T2);
+    if (cfg->out_offset < 0 || cfg->out_offset % T2 || cfg->out_offset + N > F)
+        return fail(ADSP_ERR_ARG, "out_offset %d must be a multiple of %d with out_offset + N <= F", cfg->out_offset, T2);
+    // kept sample i sits at input-time o - lookback + out_offset + i; it may not lie beyond the newest chunk
+    if (cfg->out_offset > cfg->lookback)
+        return fail(ADSP_ERR_ARG, "out_offset %d > lookback %d: kept samples would need future input", cfg->out_offset, cfg->lookback);
+    int slots = cfg->ring_slots == 0 ? cfg->history_chunks + 1 : cfg->ring_slots;
+    if (slots < cfg->history_chunks + 1) return fail(ADSP_ERR_ARG, "ring_slots must be >= history_chunks + 1");
+
+    int ndev = 0;
+    rc = adsp_device_count(&ndev);
+    if (rc) return rc;
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(ADSP_ERR_ARG, "device_id %d out of range (%d devices)", cfg->device_id, ndev);
+
+    adsp_engine* e = new adsp_engine();
+    e->cfg = *cfg;
+    e->cfg.ring_slots = slots;
+    e->plan = pl;
+    e->M = F / 2;
+    e->logN = ilog2(N);
+    e->block_outputs = N;
+    e->ring = nullptr;
+    e->ring_pos = slots - 1;
+    e->tw = e->pair = e->pair0 = nullptr;
+    e->have_spectrum = false;
+    e->stage_in = e->stage_out = nullptr;
+    e->stage_elems = 0;
+
+    auto bail = [&](int code) {
+        adsp_destroy(e);
+        return code;
+    };
+    if ((rc = set_device(e))) return bail(rc);
+    hipError_t err;
+    if ((err = pl->prepare()) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(err)));
+    const size_t ring_bytes = (size_t)slots * e->plane() * sizeof(float);
+    if ((err = hipMalloc(&e->ring, ring_bytes)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc ring (%zu bytes): %s", ring_bytes, hipGetErrorString(err)));
+    if ((err = hipMemset(e->ring, 0, ring_bytes)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMemset: %s", hipGetErrorString(err)));
+    std::vector<float2> tw;
+    build_twiddles(*pl, tw);
+    if ((int)tw.size() != pl->tw_total) return bail(fail(ADSP_ERR_STATE, "internal: twiddle count %zu != %d", tw.size(), pl->tw_total));
+    const size_t tw_bytes = (tw.size() + 1) * sizeof(float2);
+    if ((err = hipMalloc(&e->tw, tw_bytes)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
+    if (!tw.empty() && (err = hipMemcpy(e->tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice)) != hipSuccess)
+        return bail(fail(ADSP_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(err)));
+    const int R = pl->P / 2;
+    if ((err = hipMalloc(&e->pair, (size_t)R * 3 * pl->T * sizeof(float2))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
+    if ((err = hipMalloc(&e->pair0, (size_t)(R + 1) * 3 * sizeof(float2))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
+    *out_engine = e;
+    return ADSP_OK;
+}
+
+int adsp_destroy(adsp_engine* e) {
+    if (!e) return ADSP_OK;
+    (void)hipSetDevice(e->cfg.device_id);
+    (void)hipDeviceSynchronize();
+    if (e->ring) (void)hipFree(e->ring);
+    if (e->tw) (void)hipFree(e->tw);
+    if (e->pair) (void)hipFree(e->pair);
+    if (e->pair0) (void)hipFree(e->pair0);
+    if (e->stage_in) (void)hipFree(e->stage_in);
+    if (e->stage_out) (void)hipFree(e->stage_out);
+    delete e;
+    return ADSP_OK;
+}
+
+int adsp_set_spectrum(adsp_engine* e, const float* spectrum, int n_bins) {
+    if (!e || !spectrum) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (n_bins != e->M + 1) return fail(ADSP_ERR_ARG, "n_bins %d != fft_size/2+1 = %d", n_bins, e->M + 1);
+    int rc = set_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());  // the tables may still be in use by queued launches
+    return upload_pairs(e, spectrum, nullptr);
+}
+
+int adsp_set_spectrum_device(adsp_engine* e, const float* d_spectrum, int n_bins, void* stream) {
+    if (!e || !d_spectrum) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (n_bins != e->M + 1) return fail(ADSP_ERR_ARG, "n_bins %d != fft_size/2+1 = %d", n_bins, e->M + 1);
+    int rc = set_device(e);
+    if (rc) return rc;
+    std::vector<float> host((size_t)2 * n_bins);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemcpy(host.data(), d_spectrum, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipDeviceSynchronize());
+    return upload_pairs(e, host.data(), nullptr);
+}
+
+int adsp_set_block_outputs(adsp_engine* e, int v) {
+    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    const int T2 = 2 * e->plan->T;
+    if (v <= 0 || v % T2 || e->cfg.out_offset + v > e->cfg.fft_size)
+        return fail(ADSP_ERR_ARG, "block_outputs %d must be a positive multiple of %d with out_offset + block_outputs <= fft_size", v, T2);
+    // the window must not need input newer than what a block's last output may see:
+    // newest input used by the block = o - lookback + F - 1 may exceed the data, that part is zero-filled and
+    // only feeds discarded circular positions as long as out_offset + V <= F (checked above).
+    e->block_outputs = v;
+    return ADSP_OK;
+}
+
+int adsp_reset(adsp_engine* e) {
+    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    int rc = set_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(e->ring, 0, (size_t)e->cfg.ring_slots * e->plane() * sizeof(float)));
+    e->ring_pos = e->cfg.ring_slots - 1;
+    return ADSP_OK;
+}
+
+int adsp_apply_device(adsp_engine* e, const float* d_in, float* d_out, int n_steps, void* stream_v) {
+    if (!e || !d_in || !d_out) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (n_steps <= 0) return fail(ADSP_ERR_ARG, "n_steps must be positive");
+    if (!e->have_spectrum) return fail(ADSP_ERR_STATE, "adsp_set_spectrum has not been called");
+    int rc = set_device(e);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_v;
+    if ((rc = launch(e, d_in, d_out, n_steps, stream))) return rc;
+    // carry the newest chunks into the ring (stream-ordered after the kernel)
+    const int S = e->cfg.ring_slots;
+    const int cnt = n_steps < e->cfg.history_chunks ? n_steps : e->cfg.history_chunks;
+    const size_t plane = e->plane();
+    for (int i = 0; i < cnt; ++i) {
+        const int slot = (e->ring_pos + 1 + i) % S;
+        const float* src = d_in + (size_t)(n_steps - cnt + i) * plane;
+        HIP_TRY(hipMemcpyAsync(e->ring + (size_t)slot * plane, src, plane * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    }
+    e->ring_pos = (e->ring_pos + cnt) % S;
+    return ADSP_OK;
+}
+
+int adsp_ring_acquire(adsp_engine* e, float** d_slot) {
+    if (!e || !d_slot) return fail(ADSP_ERR_ARG, "NULL argument");
+    const int slot = (e->ring_pos + 1) % e->cfg.ring_slots;
+    *d_slot = e->ring + (size_t)slot * e->plane();
+    return ADSP_OK;
+}
+
+int adsp_apply_ring(adsp_engine* e, float* d_out, void* stream_v) {
+    if (!e || !d_out) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (!e->have_spectrum) return fail(ADSP_ERR_STATE, "adsp_set_spectrum has not been called");
+    int rc = set_device(e);
+    if (rc) return rc;
+    const int slot = (e->ring_pos + 1) % e->cfg.ring_slots;
+    if ((rc = launch(e, e->ring + (size_t)slot * e->plane(), d_out, 1, (hipStream_t)stream_v))) return rc;
+    e->ring_pos = slot;
+    return ADSP_OK;
+}
+
+int adsp_apply_host(adsp_engine* e, const float* in, float* out, int n_steps) {
+    if (!e || !in || !out) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (n_steps <= 0) return fail(ADSP_ERR_ARG, "n_steps must be positive");
+    int rc = set_device(e);
+    if (rc) return rc;
+    const size_t elems = (size_t)n_steps * e->plane();
+    if (elems > e->stage_elems) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (e->stage_in) (void)hipFree(e->stage_in);
+        if (e->stage_out) (void)hipFree(e->stage_out);
+        e->stage_in = e->stage_out = nullptr;
+        e->stage_elems = 0;
+        HIP_TRY(hipMalloc(&e->stage_in, elems * sizeof(float)));
+        HIP_TRY(hipMalloc(&e->stage_out, elems * sizeof(float)));
+        e->stage_elems = elems;
+    }
+    HIP_TRY(hipMemcpy(e->stage_in, in, elems * sizeof(float), hipMemcpyHostToDevice));
+    if ((rc = adsp_apply_device(e, e->stage_in, e->stage_out, n_steps, nullptr))) return rc;
+    HIP_TRY(hipMemcpy(out, e->stage_out, elems * sizeof(float), hipMemcpyDeviceToHost));
+    return ADSP_OK;
+}
+
+int adsp_get_state(adsp_engine* e, float* host_history) {
+    if (!e || !host_history) return fail(ADSP_ERR_ARG, "NULL argument");
+    int rc = set_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    const int S = e->cfg.ring_slots, nh = e->cfg.history_chunks;
+    const size_t plane = e->plane();
+    for (int h = 0; h < nh; ++h) {  // h = 0 oldest (time step -nh)
+        const int slot = ((e->ring_pos + 1 - nh + h) % S + S) % S;
+        HIP_TRY(hipMemcpy(host_history + (size_t)h * plane, e->ring + (size_t)slot * plane, plane * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return ADSP_OK;
+}
+
+int adsp_set_state(adsp_engine* e, const float* host_history) {
+    if (!e || !host_history) return fail(ADSP_ERR_ARG, "NULL argument");
+    int rc = set_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    const int S = e->cfg.ring_slots, nh = e->cfg.history_chunks;
+    const size_t plane = e->plane();
+    for (int h = 0; h < nh; ++h) {
+        const int slot = ((e->ring_pos + 1 - nh + h) % S + S) % S;
+        HIP_TRY(hipMemcpy(e->ring + (size_t)slot * plane, host_history + (size_t)h * plane, plane * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return ADSP_OK;
+}
+
+int adsp_synchronize(adsp_engine* e, void* stream) {
+    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    int rc = set_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return ADSP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,443 @@
+// fftconv_kernel.hpp - fused overlap-save FIR kernel for gfx950 (MI355X), hand-written HIP.
+//
+// One launch = for every (channel, time block): load F = 2M real samples -> M-point complex
+// Stockham FFT in registers + LDS -> real-FFT split, multiply by the filter spectrum, re-pack
+// (all three fused in registers) -> M-point inverse FFT -> store the kept samples.
+//
+// What it replaces in the reference: the per-call numpy pipeline of
+// pyAudioDspTools/EffectFFTFilter.py:67-75 (concatenate -> fft(3N) -> * -> ifft(3N) -> slice ->
+// astype) and EffectEQ3BandFFT.py:175-211, for ONE channel per call there, for a [channels x
+// blocks] grid here.  The reference's 3N complex transforms are not reproduced: the kept slice is
+// a plain linear convolution, so a 2N real transform packed as N complex
+// points is exact and 3x cheaper.
+//
+// Design notes (CDNA4):
+//  * wave64; every thread owns P (16 or 32) complex points in VGPRs, element index tid + T*m.
+//    Every Stockham pass reads elements  j + q*M/R  (= the thread's own registers) and writes runs
+//    of S contiguous elements to LDS, so reads are always bank-conflict-free (64 consecutive
+//    8-byte elements per wave) and only the S=1 pass needs an XOR swizzle on the write side.
+//  * ds_read_b64/ds_write_b64 on interleaved (re,im) pairs; one LDS buffer of M*8 bytes per
+//    transform (32 KiB at N = 4096 -> 5 workgroups per CU).
+//  * the real-FFT split needs Z[k] and Z[M-k] together.  The last forward pass (radix P/2, two
+//    butterflies per thread) is given butterflies j and M/R - j, so both partners are produced in
+//    the same thread: the split + spectrum multiply + re-pack costs no exchange at all, and the
+//    first inverse pass consumes exactly that register distribution.
+//  * inverse FFT = forward FFT on (im, re)-swapped registers: one set of butterflies, one sign.
+//  * global loads/stores are 8 bytes per lane, 512 contiguous bytes per wave instruction; chunk
+//    selection (ring history vs. the new batch) is wave-uniform scalar work.
+//  * no MFMA: ~100 flop/sample against 8-10 B/sample of HBM traffic, the walls are HBM, LDS
+//    write bandwidth and fp32 VALU in that order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <utility>
+
+namespace adsp {
+
+struct KernelArgs {
+    const float* ring;     // [ring_slots][C][N] input history ring
+    const float* in;       // [n_steps][C][N] new input (may point into the ring)
+    float* out;            // [n_steps][C][N]
+    const float2* tw;      // pass twiddles: forward passes 1.., then inverse passes 1..
+    const float2* pair;    // [R][3][T]  (wc', g1, g2) for threads 1..T-1
+    const float2* pair0;   // [R+1][3]   thread 0's self-paired butterflies
+    int ring_pos;          // slot holding the most recent history chunk (time step -1)
+    int ring_slots;
+    int C;                 // channels
+    int n_steps;           // new chunks per channel in `in`
+    int logN;              // log2(chunk size)
+    int V;                 // outputs kept per transform
+    int nblk;              // transforms per channel in this launch
+    int lookback;          // window start = block output start - lookback
+    int j0;                // circular index of the first kept sample
+    int ncg;               // channel groups = ceil(C / channels-per-workgroup)
+};
+
+// ------------------------------------------------------------------------------------------
+// compile-time plan: M complex points, P points per thread, up to 4 forward radices.
+// Inverse radices are the forward ones reversed; the last forward radix must be P/2.
+// ------------------------------------------------------------------------------------------
+template <int M_, int P_, int NP_, int A0, int A1, int A2, int A3>
+struct Plan {
+    static constexpr int M = M_, P = P_, NP = NP_, T = M_ / P_;
+    static constexpr int fwd(int p) { return p == 0 ? A0 : p == 1 ? A1 : p == 2 ? A2 : A3; }
+    static constexpr int inv(int p) { return fwd(NP_ - 1 - p); }
+    static constexpr int rad(bool inverse, int p) { return inverse ? inv(p) : fwd(p); }
+    static constexpr int stride(bool inverse, int p) {  // S = product of the radices before pass p
+        int s = 1;
+        for (int i = 0; i < p; ++i) s *= rad(inverse, i);
+        return s;
+    }
+    static constexpr int tw_count(bool inverse) {
+        int n = 0;
+        for (int p = 1; p < NP_; ++p) n += (rad(inverse, p) - 1) * stride(inverse, p);
+        return n;
+    }
+    static constexpr int tw_offset(bool inverse, int p) {
+        int n = inverse ? tw_count(false) : 0;
+        for (int i = 1; i < p; ++i) n += (rad(inverse, i) - 1) * stride(inverse, i);
+        return n;
+    }
+    static constexpr int tw_total = tw_count(false) + tw_count(true);
+    static constexpr int RL = P_ / 2;  // radix of the paired passes
+    static_assert(fwd(NP_ - 1) == P_ / 2, "last forward radix must be P/2 (two butterflies per thread)");
+    static_assert(stride(false, NP_) == M_, "radices must multiply to M");
+};
+
+// ------------------------------------------------------------------------------------------
+// small DFTs with compile-time twiddles (forward sign, natural order in and out)
+// ------------------------------------------------------------------------------------------
+__device__ constexpr float kCos32[9] = {1.0f,
+                                        0.98078528040323044913f,
+                                        0.92387953251128675613f,
+                                        0.83146961230254523708f,
+                                        0.70710678118654752440f,
+                                        0.55557023301960222474f,
+                                        0.38268343236508977173f,
+                                        0.19509032201612826785f,
+                                        0.0f};
+
+// t = W32^IDX * o,  W32 = exp(-2*pi*i/32),  0 <= IDX < 16
+template <int IDX>
+__device__ __forceinline__ void twmul32(float o_r, float o_i, float& t_r, float& t_i) {
+    static_assert(IDX >= 0 && IDX < 16, "");
+    if constexpr (IDX == 0) {
+        t_r = o_r;
+        t_i = o_i;
+    } else if constexpr (IDX == 8) {  // -i
+        t_r = o_i;
+        t_i = -o_r;
+    } else if constexpr (IDX == 4) {  // (1-i)/sqrt2
+        t_r = (o_r + o_i) * kCos32[4];
+        t_i = (o_i - o_r) * kCos32[4];
+    } else if constexpr (IDX == 12) {  // (-1-i)/sqrt2
+        t_r = (o_i - o_r) * kCos32[4];
+        t_i = -(o_r + o_i) * kCos32[4];
+    } else {
+        constexpr float wr = IDX <= 8 ? kCos32[IDX] : -kCos32[16 - IDX];
+        constexpr float wi = -(IDX <= 8 ? kCos32[8 - IDX] : kCos32[IDX - 8]);
+        t_r = o_r * wr - o_i * wi;
+        t_i = o_r * wi + o_i * wr;
+    }
+}
+
+template <int R>
+struct Dft;
+
+template <>
+struct Dft<1> {
+    static __device__ __forceinline__ void run(const float (&xr)[1], const float (&xi)[1], float (&yr)[1],
+                                               float (&yi)[1]) {
+        yr[0] = xr[0];
+        yi[0] = xi[0];
+    }
+};
+
+template <>
+struct Dft<2> {
+    static __device__ __forceinline__ void run(const float (&xr)[2], const float (&xi)[2], float (&yr)[2],
+                                               float (&yi)[2]) {
+        yr[0] = xr[0] + xr[1];
+        yi[0] = xi[0] + xi[1];
+        yr[1] = xr[0] - xr[1];
+        yi[1] = xi[0] - xi[1];
+    }
+};
+
+template <int R>
+struct Dft {
+    static constexpr int H = R / 2;
+    template <int K>
+    static __device__ __forceinline__ void combine(const float (&Er)[H], const float (&Ei)[H], const float (&Or)[H],
+                                                   const float (&Oi)[H], float (&yr)[R], float (&yi)[R]) {
+        float tr, ti;
+        twmul32<K*(32 / R)>(Or[K], Oi[K], tr, ti);
+        yr[K] = Er[K] + tr;
+        yi[K] = Ei[K] + ti;
+        yr[K + H] = Er[K] - tr;
+        yi[K + H] = Ei[K] - ti;
+    }
+    template <int... K>
+    static __device__ __forceinline__ void combine_all(std::integer_sequence<int, K...>, const float (&Er)[H],
+                                                       const float (&Ei)[H], const float (&Or)[H],
+                                                       const float (&Oi)[H], float (&yr)[R], float (&yi)[R]) {
+        (combine<K>(Er, Ei, Or, Oi, yr, yi), ...);
+    }
+    static __device__ __forceinline__ void run(const float (&xr)[R], const float (&xi)[R], float (&yr)[R],
+                                               float (&yi)[R]) {
+        float er[H], ei[H], odr[H], odi[H], Er[H], Ei[H], Or[H], Oi[H];
+#pragma unroll
+        for (int q = 0; q < H; ++q) {
+            er[q] = xr[2 * q];
+            ei[q] = xi[2 * q];
+            odr[q] = xr[2 * q + 1];
+            odi[q] = xi[2 * q + 1];
+        }
+        Dft<H>::run(er, ei, Er, Ei);
+        Dft<H>::run(odr, odi, Or, Oi);
+        combine_all(std::make_integer_sequence<int, H>{}, Er, Ei, Or, Oi, yr, yi);
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// LDS addressing.  The exchange written by a pass with S == 1 (runs of R contiguous elements per
+// thread) is XOR-swizzled so that 16 consecutive butterflies hit 16 different 8-byte bank pairs;
+// later passes write runs of S >= 8 contiguous elements and need nothing.
+// ------------------------------------------------------------------------------------------
+template <int R, bool SWZ>
+__device__ __forceinline__ int lds_phys(int a) {
+    if constexpr (!SWZ) {
+        return a;
+    } else {
+        constexpr int mask = (R < 16 ? R : 16) - 1;
+        constexpr int sh = R <= 16 ? 4 : 5;
+        return a ^ ((a >> sh) & mask);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// one Stockham pass: twiddle, DFT-R on the thread's NB = P/R butterflies, in place in registers
+// ------------------------------------------------------------------------------------------
+template <class PL, bool INV, int p>
+struct Pass {
+    static constexpr int P = PL::P, T = PL::T, M = PL::M;
+    static constexpr int R = PL::rad(INV, p);
+    static constexpr int S = PL::stride(INV, p);
+    static constexpr int NB = P / R;
+    static constexpr bool PAIRED = INV ? (p == 0) : (p == PL::NP - 1);
+    static constexpr bool LAST = (p == PL::NP - 1);
+    static constexpr int TWOFF = PL::tw_offset(INV, p);
+    static_assert(!PAIRED || NB == 2, "paired pass needs exactly two butterflies per thread");
+
+    static __device__ __forceinline__ int bfly(int i, int tid, int ja, int jb) {
+        if constexpr (PAIRED) return i == 0 ? ja : jb;
+        return tid + T * i;
+    }
+
+    static __device__ __forceinline__ void compute(float (&ar)[P], float (&ai)[P], const float2* __restrict__ tw,
+                                                   int tid, int ja, int jb) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            float ur[R], ui[R], vr[R], vi[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                ur[q] = ar[i + q * NB];
+                ui[q] = ai[i + q * NB];
+            }
+            if constexpr (S > 1) {
+                const int jlo = bfly(i, tid, ja, jb) & (S - 1);
+#pragma unroll
+                for (int q = 1; q < R; ++q) {
+                    const float2 w = tw[TWOFF + (q - 1) * S + jlo];
+                    const float xr = ur[q], xi = ui[q];
+                    ur[q] = xr * w.x - xi * w.y;
+                    ui[q] = xr * w.y + xi * w.x;
+                }
+            }
+            Dft<R>::run(ur, ui, vr, vi);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                ar[i + r * NB] = vr[r];
+                ai[i + r * NB] = vi[r];
+            }
+        }
+    }
+
+    // scatter the pass outputs: element (j_hi*R + r)*S + j_lo
+    static __device__ __forceinline__ void write(const float (&ar)[P], const float (&ai)[P], float2* lds, int tid,
+                                                 int ja, int jb) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int j = bfly(i, tid, ja, jb);
+            const int jlo = j & (S - 1);
+            const int base = (j - jlo) * R + jlo;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                lds[lds_phys<R, S == 1>(base + r * S)] = make_float2(ar[i + r * NB], ai[i + r * NB]);
+            }
+        }
+    }
+
+    // gather what the NEXT pass needs.  Normally element tid + T*m -> register m; when the next
+    // pass is the paired one, butterflies ja/jb: element j + q*(M/Rn) -> register i + 2q.
+    static __device__ __forceinline__ void read(float (&ar)[P], float (&ai)[P], const float2* lds, int tid, int ja,
+                                                int jb) {
+        constexpr bool NEXT_PAIRED = !INV && (p + 1 == PL::NP - 1);
+        if constexpr (!NEXT_PAIRED) {
+#pragma unroll
+            for (int m = 0; m < P; ++m) {
+                const float2 v = lds[lds_phys<R, S == 1>(tid + T * m)];
+                ar[m] = v.x;
+                ai[m] = v.y;
+            }
+        } else {
+            constexpr int Rn = PL::RL;
+#pragma unroll
+            for (int q = 0; q < Rn; ++q) {
+                const float2 va = lds[lds_phys<R, S == 1>(ja + q * (M / Rn))];
+                const float2 vb = lds[lds_phys<R, S == 1>(jb + q * (M / Rn))];
+                ar[2 * q] = va.x;
+                ai[2 * q] = va.y;
+                ar[2 * q + 1] = vb.x;
+                ai[2 * q + 1] = vb.y;
+            }
+        }
+    }
+};
+
+template <class PL, bool INV, int p>
+__device__ __forceinline__ void run_passes(float (&ar)[PL::P], float (&ai)[PL::P], float2* lds,
+                                           const float2* __restrict__ tw, int tid, int ja, int jb) {
+    using PS = Pass<PL, INV, p>;
+    PS::compute(ar, ai, tw, tid, ja, jb);
+    if constexpr (!PS::LAST) {
+        if constexpr (INV || p > 0) __syncthreads();  // everyone is done reading the previous exchange
+        PS::write(ar, ai, lds, tid, ja, jb);
+        __syncthreads();
+        PS::read(ar, ai, lds, tid, ja, jb);
+        run_passes<PL, INV, p + 1>(ar, ai, lds, tw, tid, ja, jb);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// real-FFT split  +  spectrum multiply  +  re-pack for the inverse, on one (k, M-k) pair.
+//   wc = -i*W_2M^k,  g1 = H[k]/(4M),  g2 = conj(H[M-k])/(4M)
+//   in : za = Z[k], zb = Z[M-k]        out: za = Zy[k]/M, zb = Zy[M-k]/M
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pair_op(float& zar, float& zai, float& zbr, float& zbi, const float2 wc,
+                                        const float2 g1, const float2 g2) {
+    const float ur = zar + zbr, ui = zai - zbi;  // U = Za + conj(Zb)
+    const float dr = zar - zbr, di = zai + zbi;  // D = Za - conj(Zb)
+    const float br = wc.x * dr - wc.y * di, bi = wc.x * di + wc.y * dr;
+    const float x1r = ur + br, x1i = ui + bi;  // 2 X[k]
+    const float x2r = ur - br, x2i = ui - bi;  // 2 conj(X[M-k])
+    const float pr = g1.x * x1r - g1.y * x1i, pi = g1.x * x1i + g1.y * x1r;
+    const float qr = g2.x * x2r - g2.y * x2i, qi = g2.x * x2i + g2.y * x2r;
+    const float er = pr + qr, ei = pi + qi;
+    const float odr = pr - qr, odi = pi - qi;
+    const float opr = wc.x * odr + wc.y * odi, opi = wc.x * odi - wc.y * odr;  // conj(wc) * Od
+    zar = er + opr;
+    zai = ei + opi;
+    zbr = er - opr;
+    zbi = opi - ei;
+}
+
+template <class PL>
+__device__ __forceinline__ void spectrum_stage(float (&xr)[PL::P], float (&xi)[PL::P],
+                                               const float2* __restrict__ pair, const float2* __restrict__ pair0,
+                                               int tid) {
+    constexpr int R = PL::RL, T = PL::T;
+    // registers: butterfly a (j = ja) output r -> [2r];  butterfly b (j = jb) output r -> [2r+1]
+    if (tid != 0) {
+        // k = tid + 2T*r pairs with M-k = jb + 2T*(R-1-r)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float2 wc = pair[(r * 3 + 0) * T + tid];
+            const float2 g1 = pair[(r * 3 + 1) * T + tid];
+            const float2 g2 = pair[(r * 3 + 2) * T + tid];
+            pair_op(xr[2 * r], xi[2 * r], xr[2 * (R - 1 - r) + 1], xi[2 * (R - 1 - r) + 1], wc, g1, g2);
+        }
+    } else {
+        // thread 0 owns the two self-paired butterflies j = 0 and j = T.
+        // entry 0: k = 0 (DC + Nyquist), entry 1: k = M/2, entries 2..: a-pairs r = 1..R/2-1
+        // (k = 2T r with 2T (R-r)), then b-pairs r = 0..R/2-1 (k = T + 2T r with T + 2T (R-1-r)).
+        {
+            float tr = xr[0], ti = xi[0];
+            pair_op(xr[0], xi[0], tr, ti, pair0[0], pair0[1], pair0[2]);
+        }
+        {
+            float tr = xr[R], ti = xi[R];  // register 2*(R/2)
+            pair_op(xr[R], xi[R], tr, ti, pair0[3], pair0[4], pair0[5]);
+        }
+#pragma unroll
+        for (int r = 1; r < R / 2; ++r) {
+            const int e = 2 + (r - 1);
+            pair_op(xr[2 * r], xi[2 * r], xr[2 * (R - r)], xi[2 * (R - r)], pair0[e * 3], pair0[e * 3 + 1],
+                    pair0[e * 3 + 2]);
+        }
+#pragma unroll
+        for (int r = 0; r < R / 2; ++r) {
+            const int e = 2 + (R / 2 - 1) + r;
+            pair_op(xr[2 * r + 1], xi[2 * r + 1], xr[2 * (R - 1 - r) + 1], xi[2 * (R - 1 - r) + 1], pair0[e * 3],
+                    pair0[e * 3 + 1], pair0[e * 3 + 2]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// the kernel: one workgroup = CPB channels x one time block
+// ------------------------------------------------------------------------------------------
+template <class PL, int CPB>
+__global__ __launch_bounds__(PL::T* CPB) void fftconv_kernel(const KernelArgs a) {
+    constexpr int M = PL::M, P = PL::P, T = PL::T;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* lds = reinterpret_cast<float2*>(smem_raw);
+
+    const int tid = static_cast<int>(threadIdx.x) % T;
+    const int grp = static_cast<int>(threadIdx.x) / T;
+    lds += grp * M;
+
+    // blockIdx -> (channel group, time block).  Blocks b % 8 land on XCD b % 8 (observed, speed
+    // only): keep one channel group's consecutive time blocks on one XCD so the overlapping part
+    // of their windows is served by that XCD's L2.
+    const int lin = static_cast<int>(blockIdx.x);
+    const int xcd = lin & 7;
+    const int idx = lin >> 3;
+    const int cgl = idx / a.nblk;
+    const int blk = idx - cgl * a.nblk;
+    const int cg = cgl * 8 + xcd;
+    if (cg >= a.ncg) return;  // whole workgroup leaves together
+    const int c = cg * CPB + grp;
+    const bool chan_ok = c < a.C;
+
+    const int N = 1 << a.logN;
+    const int o = blk * a.V;            // first output-time of this block
+    const int t0 = o - a.lookback;      // first input-time of the window (multiple of 2T)
+    const size_t plane = static_cast<size_t>(a.C) << a.logN;  // one [C][N] chunk batch
+    const size_t chan_off = (static_cast<size_t>(c) << a.logN) + 2 * tid;
+
+    float xr[P], xi[P];
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+        const int tau = t0 + 2 * T * m;  // wave-uniform
+        const int q = tau >> a.logN;     // chunk index (floor), < 0 = history
+        const int off = tau & (N - 1);
+        float2 v = make_float2(0.f, 0.f);
+        if (chan_ok && q < a.n_steps) {
+            const float* base;
+            if (q < 0) {
+                int slot = a.ring_pos + 1 + q;
+                slot += (slot < 0) ? a.ring_slots : 0;
+                base = a.ring + static_cast<size_t>(slot) * plane;
+            } else {
+                base = a.in + static_cast<size_t>(q) * plane;
+            }
+            v = *reinterpret_cast<const float2*>(base + chan_off + off);
+        }
+        xr[m] = v.x;
+        xi[m] = v.y;
+    }
+
+    const int ja = tid;
+    const int jb = (tid == 0) ? T : 2 * T - tid;
+
+    run_passes<PL, false, 0>(xr, xi, lds, a.tw, tid, ja, jb);
+    spectrum_stage<PL>(xr, xi, a.pair, a.pair0, tid);
+    run_passes<PL, true, 0>(xi, xr, lds, a.tw, tid, ja, jb);  // inverse = forward on swapped parts
+
+    const int total = a.n_steps << a.logN;
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+        const int rel = 2 * T * m - a.j0;  // wave-uniform
+        if (rel >= 0 && rel < a.V) {
+            const int tau = o + rel;
+            if (chan_ok && tau < total) {
+                const int k = tau >> a.logN;
+                const int off = tau & (N - 1);
+                float* dst = a.out + static_cast<size_t>(k) * plane + chan_off + off;
+                *reinterpret_cast<float2*>(dst) = make_float2(xr[m], xi[m]);
+            }
+        }
+    }
+}
+
+}  // namespace adsp

@@ -1,0 +1,146 @@
+"""Host-side filter design (float64) and overlap-save geometry.
+
+Everything here runs once per device construction, like the reference's ``__init__`` bodies
+(pyAudioDspTools/EffectFFTFilter.py:18-47, :91-123; EffectEQ3BandFFT.py:47-153).  The reference
+keeps four/one 3N-point complex spectra and recombines them on every call; here each device is
+reduced to ONE time-domain FIR whose 2N-point real spectrum is handed to the
+GPU engine.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+
+def filter_length(chunk_size):
+    """L = N//2 - 1 (EffectFFTFilter.py:22); d = (L-1)//2 is the look-ahead of the kept slice."""
+    taps = int(chunk_size) // 2 - 1
+    return taps, (taps - 1) // 2
+
+
+def _lowpass(cutoff_hz, fs, taps, window):
+    n = np.arange(taps, dtype=np.float64) - (taps - 1) / 2
+    h = np.sinc(2 * cutoff_hz / fs * n) * window
+    return h / h.sum()
+
+
+def _invert(h):
+    g = -h
+    g[(len(h) - 1) // 2] += 1.0
+    return g
+
+
+def highcut_kernel(cutoff_hz, fs, chunk_size):
+    """Blackman windowed-sinc low-pass, unity DC gain (EffectFFTFilter.py:28-37)."""
+    taps, _ = filter_length(chunk_size)
+    return _lowpass(cutoff_hz, fs, taps, np.blackman(taps))
+
+
+def lowcut_kernel(cutoff_hz, fs, chunk_size):
+    """Spectral inversion of the low-pass (EffectFFTFilter.py:101-113)."""
+    return _invert(highcut_kernel(cutoff_hz, fs, chunk_size))
+
+
+def eq3_kernels(lowshelf_hz, midband_hz, highshelf_hz, fs, chunk_size):
+    """The four Kaiser(6.0) kernels of EffectEQ3BandFFT.py:70-133 with their 0.75x / 1.25x cutoffs."""
+    taps, _ = filter_length(chunk_size)
+    w = np.kaiser(taps, 6.0)
+    return dict(
+        highshelf=_invert(_lowpass(highshelf_hz - highshelf_hz / 4, fs, taps, w)),
+        lowshelf=_lowpass(lowshelf_hz + lowshelf_hz / 4, fs, taps, w),
+        mid_lowpass=_lowpass(midband_hz + midband_hz / 4, fs, taps, w),
+        mid_highpass=_invert(_lowpass(midband_hz - midband_hz / 4, fs, taps, w)),
+    )
+
+
+def eq3_composite(lowshelf_hz, lowshelf_db, midband_hz, midband_db, highshelf_hz, highshelf_db, fs, chunk_size):
+    """One (2L-1)-tap FIR equal to EffectEQ3BandFFT.apply (:179-209).
+
+    sum_b (g_b - 1) band_b + dry, with the mid band = highpass (*) lowpass (spectrum product at :188,
+    hence centred at 2d - the reference's extra mid-band delay is preserved) and dry = delta at d.
+    """
+    taps, d = filter_length(chunk_size)
+    k = eq3_kernels(lowshelf_hz, midband_hz, highshelf_hz, fs, chunk_size)
+    c = np.zeros(2 * taps - 1)
+    c[:taps] += (10 ** (highshelf_db / 20) - 1) * k["highshelf"]
+    c[:taps] += (10 ** (lowshelf_db / 20) - 1) * k["lowshelf"]
+    c += (10 ** (midband_db / 20) - 1) * np.convolve(k["mid_highpass"], k["mid_lowpass"])
+    c[d] += 1.0
+    return c
+
+
+def reference_spectrum_3n(kernel, chunk_size):
+    """The reference's inspectable ``sinc_filter`` attribute: fft of the kernel zero-padded to 3N."""
+    buf = np.zeros(3 * int(chunk_size))
+    buf[: len(kernel)] = kernel
+    return np.fft.fft(buf)
+
+
+@dataclass
+class FirStream:
+    """out[tau] = sum_t taps[t] * s[tau - latency_chunks*N + lookahead - t]  (zero history)."""
+    taps: np.ndarray
+    chunk_size: int
+    latency_chunks: int = 1
+    lookahead: int = None
+
+    def __post_init__(self):
+        self.taps = np.asarray(self.taps, dtype=np.float64)
+        if self.lookahead is None:
+            self.lookahead = filter_length(self.chunk_size)[1]
+
+    @property
+    def delay(self):
+        return self.latency_chunks * self.chunk_size - self.lookahead
+
+    def then(self, other):
+        """Series connection: kernels convolve, delays add (chain LowCut -> EQ -> HighCut)."""
+        assert other.chunk_size == self.chunk_size
+        return FirStream(np.convolve(self.taps, other.taps), self.chunk_size,
+                         self.latency_chunks + other.latency_chunks, self.lookahead + other.lookahead)
+
+
+@dataclass
+class Geometry:
+    fft_size: int
+    history_chunks: int
+    lookback: int
+    out_offset: int
+    shift: int           # zero taps prepended so that out_offset is aligned
+    max_block_outputs: int
+
+
+def overlap_save_geometry(fir: FirStream) -> Geometry:
+    """Choose F, the window position and the kept slice for the GPU engine (include/adsp.h).
+
+    Output tau is y[tau - D] with y = taps (*) s and D = delay.  The window for the block starting at
+    output-time o begins at input-time o - lookback, so output tau sits at circular index
+    (tau - o) + lookback - D + shift; it is wrap-free when lookback >= D + len(taps) - 1.
+    Everything is kept a multiple of N/4 (>= 2 * threads-per-transform for every plan).
+    """
+    n = int(fir.chunk_size)
+    if n < 64 or n & (n - 1):
+        raise ValueError(f"chunk_size {n}: this build supports powers of two in 64..8192")
+    g = n // 4
+    m = len(fir.taps)
+    d_total = fir.delay
+    if d_total <= 0:
+        raise ValueError("non-causal stream")
+    lookback = -(-(d_total + m - 1) // g) * g
+    shift = (-(lookback - d_total)) % g
+    out_offset = lookback - d_total + shift
+    for f in (2 * n, 4 * n):
+        if out_offset + n <= f:
+            break
+    else:
+        raise ValueError(f"kernel of {m} taps does not fit a 4N transform at N={n}")
+    hist = -(-lookback // n)
+    vmax = ((f - out_offset) // g) * g
+    return Geometry(f, hist, lookback, out_offset, shift, vmax)
+
+
+def engine_spectrum(fir: FirStream, geo: Geometry) -> np.ndarray:
+    """rfft of the (shift-delayed) kernel at F points, float64 -> complex64, as interleaved float32."""
+    padded = np.zeros(geo.fft_size)
+    padded[geo.shift: geo.shift + len(fir.taps)] = fir.taps
+    spec = np.fft.rfft(padded).astype(np.complex64)
+    return np.ascontiguousarray(spec).view(np.float32)

@@ -1,0 +1,158 @@
+"""Drop-in device classes: CreateHighCutFilter, CreateLowCutFilter, CreateEQ3BandFFT.
+
+Same names, positional arguments, defaults, attributes and ``.apply(chunk) -> float32[N]``
+semantics as the reference (pyAudioDspTools/EffectFFTFilter.py:5-151, EffectEQ3BandFFT.py:23-211,
+exported at pyAudioDspTools/__init__.py:20-21) - one chunk of latency, zero initial history, a
+fresh float32 array per call - but the arithmetic runs in the HIP engine.  Keyword-only extras
+(``channels``, ``device``) turn one object into a bank of independent mono channels for
+``apply_batch``; they default to the reference's one-object-one-channel behaviour.
+
+Differences that are deliberate (SURVEY.md section 7 "Hard parts"):
+  * a wrong-length chunk raises ValueError BEFORE the history is touched (the reference raises the
+    same ValueError from numpy after it has already rotated its history, EffectFFTFilter.py:63-71);
+  * the caller's array is copied to the GPU, so mutating it after apply() cannot change later
+    outputs (the reference keeps a reference to it, EffectFFTFilter.py:139-141);
+  * float64 / list inputs are accepted like the reference's ``concatenate(axis=None)`` does, but are
+    rounded to float32 on entry.
+"""
+import numpy as np
+
+from . import config
+from .design import (FirStream, eq3_composite, eq3_kernels, filter_length, highcut_kernel, lowcut_kernel,
+                     reference_spectrum_3n)
+from .engine import FirEngine
+
+
+class _FFTDevice:
+    """Shared plumbing of the three devices."""
+
+    def _setup(self, fir_taps, channels, device):
+        n = config.chunk_size
+        if n is None or config.sampling_rate is None:
+            raise RuntimeError("call config.initialize(sampling_rate, chunk_size) before creating devices")
+        self._n = int(n)
+        self.channels = int(channels)
+        self.filter_length, d = filter_length(self._n)
+        self.array_slice_value_start = self._n + (self.filter_length // 2)
+        self.array_slice_value_end = self._n - (self.filter_length // 2)
+        self.cut_size = np.int16((self.filter_length - 1) / 2)
+        self.fir = FirStream(fir_taps, self._n, latency_chunks=1, lookahead=d)
+        self.engine = FirEngine(self.fir, channels=self.channels, device=device)
+        zeros = np.zeros(self._n) if self.channels == 1 else np.zeros((self.channels, self._n))
+        self.float32_array_input_1 = zeros
+        self.float32_array_input_2 = zeros
+        self.float32_array_input_3 = zeros
+
+    def _rotate(self, x):
+        self.float32_array_input_3 = self.float32_array_input_2
+        self.float32_array_input_2 = self.float32_array_input_1
+        self.float32_array_input_1 = x
+
+    def apply(self, float32_array_input):
+        """One chunk in, the previous chunk (filtered) out: float32 array of config.chunk_size samples."""
+        if self.channels != 1:
+            raise ValueError("this device holds several channels; use apply_batch(x[channels, chunk])")
+        flat = np.concatenate((float32_array_input,), axis=None)  # same flattening as the reference
+        if flat.size != self._n:
+            raise ValueError(f"operands could not be broadcast together: chunk has {flat.size} samples, "
+                             f"config.chunk_size was {self._n} when this device was created")
+        x = np.ascontiguousarray(flat, dtype=np.float32)
+        y = self.engine.apply_host(x.reshape(1, self._n))
+        self._rotate(float32_array_input)
+        return y.reshape(self._n)
+
+    def apply_batch(self, chunk_batch):
+        """[channels, N] (one step) or [steps, channels, N] float32 -> same shape."""
+        x = np.asarray(chunk_batch)
+        y = self.engine.apply_host(x)
+        self._rotate(x if x.ndim == 2 else x[-1])
+        return y
+
+    def reset(self):
+        self.engine.reset()
+        zeros = np.zeros(self._n) if self.channels == 1 else np.zeros((self.channels, self._n))
+        self.float32_array_input_1 = self.float32_array_input_2 = self.float32_array_input_3 = zeros
+
+
+class CreateHighCutFilter(_FFTDevice):
+    """FFT high-cut (low-pass) device.  cutoff_frequency defaults to 8000 like the reference
+    (EffectFFTFilter.py:18)."""
+
+    def __init__(self, cutoff_frequency=8000, *, channels=1, device=0):
+        self.fS = config.sampling_rate
+        self.fH = cutoff_frequency
+        taps = highcut_kernel(self.fH, self.fS, config.chunk_size)
+        self._setup(taps, channels, device)
+
+    @property
+    def sinc_filter(self):
+        """3N-point complex128 spectrum, as the reference exposes it (EffectFFTFilter.py:45-47)."""
+        return reference_spectrum_3n(self.fir.taps, self._n)
+
+
+class CreateLowCutFilter(_FFTDevice):
+    """FFT low-cut (high-pass) device.  cutoff_frequency defaults to 160 (EffectFFTFilter.py:91)."""
+
+    def __init__(self, cutoff_frequency=160, *, channels=1, device=0):
+        self.fS = config.sampling_rate
+        self.fH = cutoff_frequency
+        taps = lowcut_kernel(self.fH, self.fS, config.chunk_size)
+        self._setup(taps, channels, device)
+
+    @property
+    def sinc_filter(self):
+        return reference_spectrum_3n(self.fir.taps, self._n)
+
+
+class CreateEQ3BandFFT(_FFTDevice):
+    """3-band FFT EQ; six positional arguments, no defaults (EffectEQ3BandFFT.py:47)."""
+
+    def __init__(self, lowshelf_frequency, lowshelf_db, midband_frequency, midband_db, highshelf_frequency,
+                 highshelf_db, *, channels=1, device=0):
+        self.fS = config.sampling_rate
+        self.fH_highshelf = highshelf_frequency
+        self.highshelf_db = highshelf_db
+        self.fH_lowshelf = lowshelf_frequency
+        self.lowshelf_db = lowshelf_db
+        self.fH_midband = midband_frequency
+        self.midband_db = midband_db
+        self._bands = eq3_kernels(lowshelf_frequency, midband_frequency, highshelf_frequency, self.fS,
+                                  config.chunk_size)
+        taps = eq3_composite(lowshelf_frequency, lowshelf_db, midband_frequency, midband_db, highshelf_frequency,
+                             highshelf_db, self.fS, config.chunk_size)
+        self._setup(taps, channels, device)
+
+    @property
+    def sinc_filter_highshelf(self):
+        return reference_spectrum_3n(self._bands["highshelf"], self._n)
+
+    @property
+    def sinc_filter_lowshelf(self):
+        return reference_spectrum_3n(self._bands["lowshelf"], self._n)
+
+    @property
+    def sinc_filter_mid_lowpass(self):
+        return reference_spectrum_3n(self._bands["mid_lowpass"], self._n)
+
+    @property
+    def sinc_filter_mid_highpass(self):
+        return reference_spectrum_3n(self._bands["mid_highpass"], self._n)
+
+
+# The reference's cupy twins (EffectFFTFilterGPU.py, EffectEQ3BandFFTGPU.py) have the same surface.
+CreateHighCutFilterGPU = CreateHighCutFilter
+CreateLowCutFilterGPU = CreateLowCutFilter
+CreateEQ3BandFFTGPU = CreateEQ3BandFFT
+
+
+def fuse(*devices, channels=None, device=0, ring_slots=0):
+    """Series connection of FFT devices as ONE engine (config 5: LowCut -> EQ3 -> HighCut).
+
+    The result computes, in a single kernel per step, what feeding each device's output into the
+    next one's apply() computes in the reference: one FIR of summed length, latency = number of
+    devices chunks."""
+    fir = devices[0].fir
+    for dev in devices[1:]:
+        fir = fir.then(dev.fir)
+    ch = devices[0].channels if channels is None else channels
+    return FirEngine(fir, channels=ch, device=device, ring_slots=ring_slots)

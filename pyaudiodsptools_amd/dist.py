@@ -1,0 +1,95 @@
+"""Multi-GPU layer: channels shard, nothing else moves.
+
+Channels never interact (each reference device instance is private state, Example2.py:13-21), so
+the N-GPU job is N independent engines over contiguous channel ranges.  The only collective is ONE
+broadcast of the filter spectrum (complex64, 32 KiB at N = 4096) from rank 0 at filter
+creation/change - RCCL over xGMI on the GPU box (backend "nccl"), gloo in the CPU tests.  One
+process per GPU, launched by torchrun / torch.distributed.run.
+"""
+import os
+
+import numpy as np
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun environment; (0, 0, 1) when not distributed."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def shard_range(n_channels, world_size, rank):
+    """Contiguous, balanced channel range [lo, hi) owned by `rank` (first ranks take the remainder)."""
+    base, rem = divmod(int(n_channels), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_process_group(backend=None):
+    """Initialise torch.distributed from the environment (127.0.0.1 rendezvous by default)."""
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if backend is None:
+        import torch
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    dist.init_process_group(backend=backend)
+    return dist
+
+
+def broadcast_spectrum(spectrum_f32, src=0, device=None):
+    """Broadcast the interleaved float32 spectrum from `src`; returns (tensor, numpy copy).
+
+    Non-source ranks pass an array of the right size (contents ignored) or just its length.
+    With backend nccl the tensor lives on `device` (RCCL broadcast over xGMI)."""
+    import torch
+    import torch.distributed as dist
+    if isinstance(spectrum_f32, int):
+        spectrum_f32 = np.zeros(spectrum_f32, np.float32)
+    t = torch.from_numpy(np.ascontiguousarray(spectrum_f32, dtype=np.float32).copy())
+    if device is not None:
+        t = t.to(device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(t, src=src)
+    return t, t.detach().cpu().numpy()
+
+
+class ShardedFirBank:
+    """All channels of a job, this rank's shard on this rank's GPU.
+
+    rank 0 designs the filter; every rank receives the identical spectrum by broadcast and uploads
+    it to its own engine (bit-identical spectra across ranks by construction)."""
+
+    def __init__(self, fir, total_channels, device=0, ring_slots=0, engine_factory=None):
+        from .design import engine_spectrum, overlap_save_geometry
+        rank, _, world = env_world()
+        try:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                rank, world = dist.get_rank(), dist.get_world_size()
+        except ImportError:
+            pass
+        self.rank, self.world = rank, world
+        self.lo, self.hi = shard_range(total_channels, world, rank)
+        self.total_channels = int(total_channels)
+        geo = overlap_save_geometry(fir)
+        n_floats = 2 * (geo.fft_size // 2 + 1)
+        spec = engine_spectrum(fir, geo) if rank == 0 else np.zeros(n_floats, np.float32)
+        bdev = None
+        try:
+            import torch
+            import torch.distributed as dist
+            if dist.is_initialized() and dist.get_backend() == "nccl":
+                bdev = torch.device("cuda", device)
+        except ImportError:
+            pass
+        self.spectrum_tensor, self.spectrum = broadcast_spectrum(spec, 0, bdev)
+        if engine_factory is None:
+            from .engine import FirEngine
+            engine_factory = FirEngine
+        self.engine = engine_factory(fir, channels=self.hi - self.lo, device=device, ring_slots=ring_slots)
+        if bdev is not None:
+            self.engine.upload_spectrum_device(self.spectrum_tensor, n_floats // 2)
+        else:
+            self.engine.upload_spectrum(self.spectrum)

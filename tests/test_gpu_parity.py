@@ -1,0 +1,319 @@
+"""GPU parity: the HIP path (through the C ABI) against golden vectors from the reference, the CPU
+oracle, and size-independent properties at BASELINE.json's full sizes.  Run with -m gpu on MI355X."""
+import numpy as np
+import pytest
+
+from conftest import assert_parity, seeded_stream
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def adsp():
+    import pyaudiodsptools_amd as pkg
+    from pyaudiodsptools_amd import _capi
+    assert _capi.device_count() >= 1, "no GPU visible: the HIP path cannot run (no CPU fallback by design)"
+    return pkg
+
+
+def orc():
+    from oracle import fftfilter_oracle as o
+    return o
+
+
+KAT = {
+    # name: (factory(adsp), fs, N, seed, chunks)
+    "A": (lambda p: p.CreateLowCutFilter(800), 44100, 4096, 1234, 6),
+    "B": (lambda p: p.CreateHighCutFilter(8000), 44100, 4096, 1234, 6),
+    "C": (lambda p: p.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), 44100, 512, 1234, 6),
+    "D": (lambda p: p.CreateLowCutFilter(200), 44100, 512, 1234, 6),
+    "EQ4096": (lambda p: p.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), 44100, 4096, 77, 5),
+    "LC8192": (lambda p: p.CreateLowCutFilter(800), 96000, 8192, 78, 4),
+    "EQ8192": (lambda p: p.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), 96000, 8192, 79, 4),
+    "HC1024": (lambda p: p.CreateHighCutFilter(20000), 48000, 1024, 80, 7),
+    "EQ1024": (lambda p: p.CreateEQ3BandFFT(250, -6, 1500, 3, 6000, -2.5), 48000, 1024, 81, 7),
+    "LC2048": (lambda p: p.CreateLowCutFilter(160), 44100, 2048, 82, 5),
+    "HC256": (lambda p: p.CreateHighCutFilter(3000), 44100, 256, 83, 9),
+    "EQ128": (lambda p: p.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), 44100, 128, 84, 9),
+    "LC64": (lambda p: p.CreateLowCutFilter(2000), 44100, 64, 85, 11),
+}
+
+
+@pytest.mark.parametrize("name", sorted(KAT))
+def test_dropin_apply_matches_reference_golden(adsp, golden, name):
+    """The reference's own call pattern: config.initialize, Create*, one .apply per chunk."""
+    make, fs, n, seed, chunks = KAT[name]
+    adsp.config.initialize(fs, n)
+    dev = make(adsp)
+    x = seeded_stream(seed, chunks * n)
+    outs = [dev.apply(x[i * n:(i + 1) * n]) for i in range(chunks)]
+    assert all(o.dtype == np.float32 and o.shape == (n,) for o in outs)
+    assert_parity(np.concatenate(outs), golden["kat_streams"][name], what=name)
+
+
+def test_default_arguments_and_attributes(adsp, golden):
+    adsp.config.initialize(44100, 512)
+    hc, lc = adsp.CreateHighCutFilter(), adsp.CreateLowCutFilter()
+    assert (hc.fH, lc.fH, hc.fS, hc.filter_length) == (8000, 160, 44100, 255)
+    assert (hc.array_slice_value_start, hc.array_slice_value_end) == (512 + 127, 512 - 127)
+    assert np.abs(np.fft.ifft(hc.sinc_filter).real[:255] - golden["design"]["highcut_default_44100_512"]).max() < 1e-12
+    assert np.abs(np.fft.ifft(lc.sinc_filter).real[:255] - golden["design"]["lowcut_default_44100_512"]).max() < 1e-12
+    with pytest.raises(TypeError):
+        adsp.CreateEQ3BandFFT()  # six positionals, no defaults (EffectEQ3BandFFT.py:47)
+
+
+def test_config_is_read_at_construction_only(adsp, golden):
+    adsp.config.initialize(44100, 512)
+    dev = adsp.CreateLowCutFilter(200)
+    adsp.config.initialize(48000, 1024)  # must not affect the existing device
+    x = seeded_stream(1234, 6 * 512)
+    y = np.concatenate([dev.apply(x[i * 512:(i + 1) * 512]) for i in range(6)])
+    assert_parity(y, golden["kat_streams"]["D"], what="D after re-initialize")
+
+
+EDGES = {
+    "zeros": lambda n: np.zeros(5 * n, np.float32),
+    "imp0": lambda n: np.eye(1, 5 * n, 0, dtype=np.float32)[0],
+    "impNm1": lambda n: np.eye(1, 5 * n, n - 1, dtype=np.float32)[0],
+    "impN": lambda n: np.eye(1, 5 * n, n, dtype=np.float32)[0],
+    "dc": lambda n: np.ones(5 * n, np.float32),
+    "square": lambda n: np.where((np.arange(5 * n) // 37) % 2 == 0, 1.0, -1.0).astype(np.float32),
+}
+
+
+@pytest.mark.parametrize("edge", sorted(EDGES))
+def test_edge_inputs_G(adsp, golden, edge):
+    n = 512
+    x = EDGES[edge](n)
+    adsp.config.initialize(44100, n)
+    for tag, dev in (("lowcut_", adsp.CreateLowCutFilter(200)), ("highcut_", adsp.CreateHighCutFilter(8000)),
+                     ("eq_", adsp.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5))):
+        y = np.concatenate([dev.apply(x[i * n:(i + 1) * n]) for i in range(5)])
+        assert_parity(y, golden["kat_edges"][tag + edge], what=tag + edge)
+    if edge == "zeros":
+        assert not y.any()
+
+
+def test_input_types_and_wrong_length(adsp, golden):
+    n = 512
+    adsp.config.initialize(44100, n)
+    x64 = np.random.default_rng(5).uniform(-1, 1, 4 * n)
+    dev = adsp.CreateLowCutFilter(200)
+    y = np.concatenate([dev.apply(x64[i * n:(i + 1) * n]) for i in range(4)])
+    assert_parity(y, golden["kat_edges"]["lowcut_f64in"], what="float64 input")
+    dev = adsp.CreateHighCutFilter(8000)
+    y = np.concatenate([dev.apply(list(x64[i * n:(i + 1) * n])) for i in range(4)])
+    assert_parity(y, golden["kat_edges"]["highcut_listin"], what="list input")
+    # wrong length: ValueError like the reference, but the history must be untouched
+    dev = adsp.CreateHighCutFilter(8000)
+    first = dev.apply(x64[:n])
+    with pytest.raises(ValueError):
+        dev.apply(x64[: n - 1])
+    rest = [dev.apply(list(x64[i * n:(i + 1) * n])) for i in range(1, 4)]
+    assert_parity(np.concatenate([first] + rest), golden["kat_edges"]["highcut_listin"], what="after bad call")
+
+
+def test_example1_plumbing_F(adsp, golden):
+    g = golden["kat_example1"]
+    x = g["pcm16_first8"].astype(np.float32) / 32768
+    adsp.config.initialize(44100, 4096)
+    dev = adsp.CreateLowCutFilter(800)
+    y = np.concatenate([dev.apply(x[i * 4096:(i + 1) * 4096]) for i in range(8)])
+    assert_parity(y, g["out_first8"], what="Example1")
+
+
+def test_chain_fused_E(adsp, golden):
+    """config 5's chain as ONE engine == three reference devices in series (golden E)."""
+    n, fs = 8192, 96000
+    adsp.config.initialize(fs, n)
+    eng = adsp.fuse(adsp.CreateLowCutFilter(800), adsp.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5),
+                    adsp.CreateHighCutFilter(8000))
+    assert eng.geometry.fft_size == 4 * n and eng.geometry.history_chunks == 5
+    x = seeded_stream(4321, 12 * n).reshape(12, 1, n)
+    y = np.concatenate([eng.apply_host(x[k])[0] for k in range(12)])
+    assert_parity(y, golden["kat_chain"]["E"], what="chain streaming")
+    eng.reset()
+    y2 = eng.apply_host(x).reshape(-1)  # all 12 steps in one launch (multi-step blocks)
+    assert_parity(y2, golden["kat_chain"]["E"], what="chain offline")
+
+
+@pytest.mark.parametrize("n,channels", [(64, 37), (128, 9), (256, 5), (512, 7), (1024, 3), (2048, 2), (4096, 5), (8192, 2)])
+def test_batched_channels_vs_oracle(adsp, n, channels):
+    """Ragged channel counts (not a multiple of channels-per-workgroup), every channel checked."""
+    o = orc()
+    fs, steps = 44100, 5
+    adsp.config.initialize(fs, n)
+    rng = np.random.default_rng(n + channels)
+    x = rng.uniform(-1, 1, (steps, channels, n)).astype(np.float32)
+    for make_dev, taps in (
+        (lambda: adsp.CreateLowCutFilter(300, channels=channels), o.lowcut_taps(300, fs, n)),
+        (lambda: adsp.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5, channels=channels),
+         o.eq3_composite_taps(100, 2, 700, -4, 8000, 5, fs, n)),
+    ):
+        dev = make_dev()
+        y = np.stack([dev.apply_batch(x[k]) for k in range(steps)])
+        for c in range(channels):
+            truth = o.direct_stream_convolution(taps, x[:, c].reshape(-1), n)
+            assert_parity(y[:, c].reshape(-1), truth, what=f"N={n} ch={c}")
+
+
+@pytest.mark.parametrize("n", [512, 4096])
+def test_multistep_equals_streaming_and_state_roundtrip(adsp, n):
+    fs, channels, steps = 44100, 4, 9
+    adsp.config.initialize(fs, n)
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, (steps, channels, n)).astype(np.float32)
+    a = adsp.CreateLowCutFilter(800, channels=channels)
+    stream = np.stack([a.apply_batch(x[k]) for k in range(steps)])
+    b = adsp.CreateLowCutFilter(800, channels=channels)
+    assert b.engine.block_outputs == n + n // 2  # 1.5 N kept per 2N transform in multi-step launches
+    part1 = b.apply_batch(x[:4])
+    state = b.engine.get_state()
+    assert np.array_equal(state, x[2:4])  # the two previous chunks, oldest first
+    part2 = b.apply_batch(x[4:])
+    assert_parity(np.concatenate([part1, part2]), stream, what="multi-step vs streaming")
+    # restore the saved state into a fresh device and continue from step 4
+    c = adsp.CreateLowCutFilter(800, channels=channels)
+    c.engine.set_state(state)
+    assert_parity(c.apply_batch(x[4:]), part2, what="state round trip")
+    c.reset()
+    assert not c.engine.get_state().any()
+    assert_parity(c.apply_batch(x[:4]), part1, what="after reset")
+    # block size N as well (different transform count, same samples)
+    b.reset()
+    b.engine.set_block_outputs(n)
+    assert_parity(b.apply_batch(x), stream, what="V=N multi-step")
+
+
+def test_device_pointer_and_ring_paths(adsp):
+    """adsp_apply_device on torch tensors and the zero-copy ring path give the same stream."""
+    import torch
+    n, channels, steps = 1024, 6, 7
+    adsp.config.initialize(48000, n)
+    from pyaudiodsptools_amd import FirEngine, FirStream, design
+    fir = FirStream(design.highcut_kernel(5000, 48000, n), n)
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, (steps, channels, n)).astype(np.float32)
+    ref_eng = FirEngine(fir, channels=channels)
+    ref = ref_eng.apply_host(x)
+    xd = torch.from_numpy(x).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    # per-step device calls
+    e1 = FirEngine(fir, channels=channels)
+    yd = torch.empty_like(xd)
+    for k in range(steps):
+        e1.apply_device(xd[k], yd[k], 1, s)
+    torch.cuda.synchronize()
+    assert_parity(yd.cpu().numpy(), ref, what="apply_device per step")
+    # zero-copy ring: the producer writes into the slot the engine hands out
+    e2 = FirEngine(fir, channels=channels, ring_slots=5)
+    y2 = torch.empty_like(xd)
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    for k in range(steps):
+        slot = e2.ring_acquire()
+        assert hip.hipMemcpyAsync(slot, xd[k].data_ptr(), channels * n * 4, 3, s) == 0
+        e2.apply_ring(y2[k], s)
+    torch.cuda.synchronize()
+    assert_parity(y2.cpu().numpy(), ref, what="ring path")
+
+
+def test_spectrum_update_keeps_history(adsp):
+    n, channels = 512, 3
+    adsp.config.initialize(44100, n)
+    from pyaudiodsptools_amd import FirStream, design
+    o = orc()
+    rng = np.random.default_rng(9)
+    x = rng.uniform(-1, 1, (6, channels, n)).astype(np.float32)
+    dev = adsp.CreateLowCutFilter(200, channels=channels)
+    dev.apply_batch(x[:3])
+    new_taps = design.lowcut_kernel(1000, 44100, n)
+    dev.engine.set_fir(FirStream(new_taps, n))
+    y = dev.apply_batch(x[3:])
+    truth = np.stack([o.direct_stream_convolution(new_taps, x[:, c].reshape(-1), n)[3 * n:] for c in range(channels)])
+    assert_parity(y.transpose(1, 0, 2).reshape(channels, -1), truth, what="after set_fir")
+
+
+def test_errors_cross_the_abi_as_exceptions(adsp):
+    from pyaudiodsptools_amd import _capi
+    adsp.config.initialize(44100, 3000)
+    with pytest.raises(ValueError):
+        adsp.CreateLowCutFilter(800)  # chunk size without a plan (non power of two): documented limitation
+    adsp.config.initialize(44100, 512)
+    dev = adsp.CreateLowCutFilter(800, channels=2)
+    with pytest.raises(ValueError):
+        dev.apply(np.zeros(512, np.float32))  # multi-channel device needs apply_batch
+    with pytest.raises(ValueError):
+        dev.apply_batch(np.zeros((3, 512), np.float32))
+    with pytest.raises(_capi.AdspError):
+        dev.engine.set_block_outputs(100)
+
+
+# ---- BASELINE.json full sizes: properties that do not need the oracle at full size --------------
+def test_config2_full_size_properties(adsp):
+    """4096 channels x 4096 samples, LowCut(800): impulse response == taps, linearity, and a sampled
+    oracle check, through the device-pointer path."""
+    import torch
+    o = orc()
+    n, channels, steps, fs = 4096, 4096, 4, 44100
+    adsp.config.initialize(fs, n)
+    dev = adsp.CreateLowCutFilter(800, channels=channels)
+    eng = dev.engine
+    taps = o.lowcut_taps(800, fs, n)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=g)
+    x[:, 0] = 0
+    x[0, 0, 17] = 1.0  # channel 0: unit impulse at sample 17
+    x[:, 1] = 0        # channel 1: silence
+    y = torch.empty_like(x)
+    s = torch.cuda.current_stream().cuda_stream
+    for k in range(steps):
+        eng.apply_device(x[k], y[k], 1, s)
+    torch.cuda.synchronize()
+    yh = y.cpu().numpy()
+    assert np.isfinite(yh).all()
+    assert not yh[:, 1].any()
+    d = n // 4 - 1
+    imp = yh[:, 0].reshape(-1)
+    start = n - d + 17  # out[tau] = sum c[t] s[tau - N + d - t]
+    assert np.abs(imp[start:start + len(taps)] - taps).max() <= 1e-5 * np.abs(taps).max()
+    assert np.abs(np.delete(imp, np.arange(start, start + len(taps)))).max() <= 2e-6
+    xh = x.cpu().numpy()
+    for c in (2, 1777, channels - 1):
+        truth = o.direct_stream_convolution(taps, xh[:, c].reshape(-1), n)
+        assert_parity(yh[:, c].reshape(-1), truth, what=f"config2 ch {c}")
+    # linearity / channel independence: filter(a*x + b*z) == a*filter(x) + b*filter(z), in one multi-step launch
+    eng.reset()
+    z = torch.empty_like(x).uniform_(-1, 1, generator=g)
+    mix = 0.5 * x + 0.25 * z
+    y_mix, y_z = torch.empty_like(x), torch.empty_like(x)
+    eng.apply_device(mix, y_mix, steps, s)
+    eng.reset()
+    eng.apply_device(z, y_z, steps, s)
+    torch.cuda.synchronize()
+    lin = 0.5 * y + 0.25 * y_z
+    assert float((y_mix - lin).abs().max()) <= 1e-5 * float(lin.abs().max())
+
+
+def test_config3_full_size_eq_stereo_pairs(adsp):
+    """2048 stereo pairs x 512 samples, EQ3: L and R of a pair fed the same signal give the same output;
+    sampled channels match the oracle."""
+    import torch
+    o = orc()
+    n, channels, steps, fs = 512, 4096, 6, 44100
+    adsp.config.initialize(fs, n)
+    dev = adsp.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5, channels=channels)
+    g = torch.Generator(device="cuda").manual_seed(6)
+    mono = torch.empty((steps, channels // 2, n), device="cuda").uniform_(-1, 1, generator=g)
+    x = mono.repeat_interleave(2, dim=1).contiguous()
+    y = torch.empty_like(x)
+    s = torch.cuda.current_stream().cuda_stream
+    for k in range(steps):
+        dev.engine.apply_device(x[k], y[k], 1, s)
+    torch.cuda.synchronize()
+    assert torch.equal(y[:, 0::2], y[:, 1::2])
+    taps = o.eq3_composite_taps(100, 2, 700, -4, 8000, 5, fs, n)
+    xh, yh = x.cpu().numpy(), y.cpu().numpy()
+    for c in (0, 1234, channels - 1):
+        assert_parity(yh[:, c].reshape(-1), o.direct_stream_convolution(taps, xh[:, c].reshape(-1), n), what=f"config3 ch {c}")
