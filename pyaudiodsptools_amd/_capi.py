@@ -69,6 +69,14 @@ def load():
             f"{LIB_PATH} is missing: the HIP extension has not been built. "
             "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C pyaudiodsptools_amd/csrc`. "
             "pyaudiodsptools_amd has no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64.
+    # If libadsp pulled in /opt/rocm's copy first, torch.cuda would later find "no HIP GPUs".  Loading
+    # torch's runtime first makes libadsp's DT_NEEDED resolve (by SONAME) to the same copy, so torch
+    # tensors, streams and this library share one device context.  torch is optional.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
