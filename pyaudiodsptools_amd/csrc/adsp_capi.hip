@@ -39,7 +39,7 @@ int fail(int code, const char* fmt, ...) {
 // plan registry
 // ------------------------------------------------------------------------------------------
 struct PlanInfo {
-    int M, P, T, CPB, NP;
+    int M, FN, P, T, CPB, NP;  // FN = fft_size / chunk_size
     int rad[4];
     int tw_total;
     int lds_bytes;
@@ -47,41 +47,48 @@ struct PlanInfo {
     hipError_t (*prepare)();
 };
 
-template <class PL, int CPB>
+template <class PL, int CPB, int FN>
 hipError_t launch_impl(const adsp::KernelArgs& a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((adsp::fftconv_kernel<PL, CPB>), dim3(grid), dim3(PL::T * CPB), PL::M * CPB * sizeof(float2), s, a);
+    hipLaunchKernelGGL((adsp::fftconv_kernel<PL, CPB, FN>), dim3(grid), dim3(PL::T * CPB), PL::M * CPB * sizeof(float2), s, a);
     return hipGetLastError();
 }
 
-template <class PL, int CPB>
+template <class PL, int CPB, int FN>
 hipError_t prepare_impl() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&adsp::fftconv_kernel<PL, CPB>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&adsp::fftconv_kernel<PL, CPB, FN>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, PL::M * CPB * (int)sizeof(float2));
 }
 
-template <class PL, int CPB>
+template <class PL, int CPB, int FN>
 constexpr PlanInfo make_plan() {
-    return PlanInfo{PL::M, PL::P, PL::T, CPB, PL::NP, {PL::fwd(0), PL::fwd(1), PL::fwd(2), PL::fwd(3)},
-                    PL::tw_total, PL::M * CPB * (int)sizeof(float2), &launch_impl<PL, CPB>, &prepare_impl<PL, CPB>};
+    return PlanInfo{PL::M, FN, PL::P, PL::T, CPB, PL::NP, {PL::fwd(0), PL::fwd(1), PL::fwd(2), PL::fwd(3)},
+                    PL::tw_total, PL::M * CPB * (int)sizeof(float2), &launch_impl<PL, CPB, FN>, &prepare_impl<PL, CPB, FN>};
 }
 
 using adsp::Plan;
 // M (complex points) -> plan.  Last forward radix is always P/2 (see fftconv_kernel.hpp).
 const PlanInfo kPlans[] = {
-    make_plan<Plan<64, 16, 2, 8, 8, 1, 1>, 16>(),
-    make_plan<Plan<128, 16, 2, 16, 8, 1, 1>, 8>(),
-    make_plan<Plan<256, 16, 3, 4, 8, 8, 1>, 4>(),
-    make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 2>(),
-    make_plan<Plan<1024, 16, 3, 16, 8, 8, 1>, 1>(),
-    make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1>(),
-    make_plan<Plan<4096, 32, 3, 16, 16, 16, 1>, 1>(),
-    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1>(),
-    make_plan<Plan<16384, 32, 4, 32, 2, 16, 16>, 1>(),
+    make_plan<Plan<64, 16, 2, 8, 8, 1, 1>, 16, 2>(),
+    make_plan<Plan<128, 16, 2, 16, 8, 1, 1>, 8, 2>(),
+    make_plan<Plan<128, 16, 2, 16, 8, 1, 1>, 8, 4>(),
+    make_plan<Plan<256, 16, 3, 4, 8, 8, 1>, 4, 2>(),
+    make_plan<Plan<256, 16, 3, 4, 8, 8, 1>, 4, 4>(),
+    make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 2, 2>(),
+    make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 2, 4>(),
+    make_plan<Plan<1024, 16, 3, 16, 8, 8, 1>, 1, 2>(),
+    make_plan<Plan<1024, 16, 3, 16, 8, 8, 1>, 1, 4>(),
+    make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 2>(),
+    make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 4>(),
+    make_plan<Plan<4096, 32, 3, 16, 16, 16, 1>, 1, 2>(),
+    make_plan<Plan<4096, 32, 3, 16, 16, 16, 1>, 1, 4>(),
+    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1, 2>(),
+    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1, 4>(),
+    make_plan<Plan<16384, 32, 4, 32, 2, 16, 16>, 1, 4>(),
 };
 
-const PlanInfo* find_plan(int M) {
+const PlanInfo* find_plan(int M, int FN) {
     for (const PlanInfo& p : kPlans)
-        if (p.M == M) return &p;
+        if (p.M == M && p.FN == FN) return &p;
     return nullptr;
 }
 
@@ -95,7 +102,7 @@ int ilog2(int v) {
 int check_geometry(int N, int F, const PlanInfo** out) {
     if (!is_pow2(N) || N < 64 || N > 8192) return fail(ADSP_ERR_ARG, "chunk_size %d: need a power of two in 64..8192", N);
     if (F != 2 * N && F != 4 * N) return fail(ADSP_ERR_ARG, "fft_size %d: need 2*chunk_size or 4*chunk_size", F);
-    const PlanInfo* p = find_plan(F / 2);
+    const PlanInfo* p = find_plan(F / 2, F / N);
     if (!p) return fail(ADSP_ERR_ARG, "no kernel plan for %d complex points", F / 2);
     if (out) *out = p;
     return ADSP_OK;
@@ -147,6 +154,7 @@ struct adsp_engine {
     float2* tw;
     float2* pair;
     float2* pair0;
+    float* zeros;  // chunk_size zero floats
     bool have_spectrum;
     float* stage_in;
     float* stage_out;
@@ -201,11 +209,11 @@ int launch(adsp_engine* e, const float* d_in, float* d_out, int n_steps, hipStre
     a.tw = e->tw;
     a.pair = e->pair;
     a.pair0 = e->pair0;
+    a.zeros = e->zeros;
     a.ring_pos = e->ring_pos;
     a.ring_slots = c.ring_slots;
     a.C = c.n_channels;
     a.n_steps = n_steps;
-    a.logN = e->logN;
     a.V = n_steps == 1 ? c.chunk_size : e->block_outputs;
     const long long total = (long long)n_steps * c.chunk_size;
     a.nblk = (int)((total + a.V - 1) / a.V);
@@ -290,6 +298,7 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     e->ring = nullptr;
     e->ring_pos = slots - 1;
     e->tw = e->pair = e->pair0 = nullptr;
+    e->zeros = nullptr;
     e->have_spectrum = false;
     e->stage_in = e->stage_out = nullptr;
     e->stage_elems = 0;
@@ -314,6 +323,8 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     const int R = pl->P / 2;
     if ((err = hipMalloc(&e->pair, (size_t)R * 3 * pl->T * sizeof(float2))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
     if ((err = hipMalloc(&e->pair0, (size_t)(R + 1) * 3 * sizeof(float2))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
+    if ((err = hipMalloc(&e->zeros, (size_t)N * sizeof(float))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
+    if ((err = hipMemset(e->zeros, 0, (size_t)N * sizeof(float))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMemset: %s", hipGetErrorString(err)));
     *out_engine = e;
     return ADSP_OK;
 }
@@ -326,6 +337,7 @@ int adsp_destroy(adsp_engine* e) {
     if (e->tw) (void)hipFree(e->tw);
     if (e->pair) (void)hipFree(e->pair);
     if (e->pair0) (void)hipFree(e->pair0);
+    if (e->zeros) (void)hipFree(e->zeros);
     if (e->stage_in) (void)hipFree(e->stage_in);
     if (e->stage_out) (void)hipFree(e->stage_out);
     delete e;

@@ -40,11 +40,11 @@ struct KernelArgs {
     const float2* tw;      // pass twiddles: forward passes 1.., then inverse passes 1..
     const float2* pair;    // [R][3][T]  (wc', g1, g2) for threads 1..T-1
     const float2* pair0;   // [R+1][3]   thread 0's self-paired butterflies
+    const float* zeros;    // >= N zero floats (stands in for chunks that do not exist)
     int ring_pos;          // slot holding the most recent history chunk (time step -1)
     int ring_slots;
     int C;                 // channels
     int n_steps;           // new chunks per channel in `in`
-    int logN;              // log2(chunk size)
     int V;                 // outputs kept per transform
     int nblk;              // transforms per channel in this launch
     int lookback;          // window start = block output start - lookback
@@ -364,11 +364,50 @@ __device__ __forceinline__ void spectrum_stage(float (&xr)[PL::P], float (&xi)[P
 }
 
 // ------------------------------------------------------------------------------------------
+// window load / kept-sample store with compile-time chunk geometry.
+// FN = F/N (2 or 4).  MPC = P/FN registers per chunk; windows and kept ranges start on quarter-chunk
+// boundaries, so (phase RQ in 0..3, register m) -> (chunk index, offset) is known at compile time.
+// ------------------------------------------------------------------------------------------
+template <class PL, int FN, int RQ>
+__device__ __forceinline__ void load_window(const float* const (&cb)[FN + 1], float (&xr)[PL::P], float (&xi)[PL::P]) {
+    constexpr int P = PL::P, T = PL::T, MPC = P / FN, Q = MPC / 4;
+    static_assert(MPC % 4 == 0, "need at least 4 registers per chunk");
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int gi = RQ * Q + m;
+        const int i = gi / MPC;
+        const int off = (gi % MPC) * 2 * T;
+        const float2 v = *reinterpret_cast<const float2*>(cb[i] + off);
+        xr[m] = v.x;
+        xi[m] = v.y;
+    }
+}
+
+template <class PL, int FN, int RQ>
+__device__ __forceinline__ void store_kept(float* const (&ob)[FN + 1], const float (&xr)[PL::P],
+                                           const float (&xi)[PL::P], int m_lo, int m_hi) {
+    constexpr int P = PL::P, T = PL::T, MPC = P / FN, Q = MPC / 4;
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+        if (m >= m_lo && m < m_hi) {  // wave-uniform
+            const int gi = RQ * Q + m;
+            const int i = gi / MPC;
+            const int off = (gi % MPC) * 2 * T;
+            *reinterpret_cast<float2*>(ob[i] + off) = make_float2(xr[m], xi[m]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // the kernel: one workgroup = CPB channels x one time block
 // ------------------------------------------------------------------------------------------
-template <class PL, int CPB>
+template <class PL, int CPB, int FN>
 __global__ __launch_bounds__(PL::T* CPB) void fftconv_kernel(const KernelArgs a) {
     constexpr int M = PL::M, P = PL::P, T = PL::T;
+    constexpr int N = 2 * M / FN;  // chunk size
+    constexpr int LOGN = __builtin_ctz(N);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2* lds = reinterpret_cast<float2*>(smem_raw);
 
@@ -387,34 +426,40 @@ __global__ __launch_bounds__(PL::T* CPB) void fftconv_kernel(const KernelArgs a)
     const int cg = cgl * 8 + xcd;
     if (cg >= a.ncg) return;  // whole workgroup leaves together
     const int c = cg * CPB + grp;
-    const bool chan_ok = c < a.C;
+    const bool chan_ok = CPB == 1 ? true : (c < a.C);
 
-    const int N = 1 << a.logN;
-    const int o = blk * a.V;            // first output-time of this block
-    const int t0 = o - a.lookback;      // first input-time of the window (multiple of 2T)
-    const size_t plane = static_cast<size_t>(a.C) << a.logN;  // one [C][N] chunk batch
-    const size_t chan_off = (static_cast<size_t>(c) << a.logN) + 2 * tid;
+    const int o = blk * a.V;        // first output-time of this block (multiple of N/4)
+    const int t0 = o - a.lookback;  // first input-time of the window (multiple of N/4)
+    const size_t plane = static_cast<size_t>(a.C) << LOGN;  // one [C][N] chunk batch
+    const size_t chan_off = (static_cast<size_t>(c) << LOGN) + 2 * tid;
 
-    float xr[P], xi[P];
+    // The window touches at most FN + 1 chunks.  Resolve each to a pointer once: ring history, new
+    // input, or the zero page for chunks that do not exist yet / channels past the end.
+    const int q0 = t0 >> LOGN;  // floor: chunk of the window start, < 0 = history
+    const float* cb[FN + 1];
 #pragma unroll
-    for (int m = 0; m < P; ++m) {
-        const int tau = t0 + 2 * T * m;  // wave-uniform
-        const int q = tau >> a.logN;     // chunk index (floor), < 0 = history
-        const int off = tau & (N - 1);
-        float2 v = make_float2(0.f, 0.f);
+    for (int i = 0; i < FN + 1; ++i) {
+        const int q = q0 + i;
+        const float* base = a.zeros + 2 * tid;
         if (chan_ok && q < a.n_steps) {
-            const float* base;
             if (q < 0) {
                 int slot = a.ring_pos + 1 + q;
                 slot += (slot < 0) ? a.ring_slots : 0;
-                base = a.ring + static_cast<size_t>(slot) * plane;
+                slot = slot < 0 ? 0 : slot;  // (older than the history: never dereferenced with data that matters)
+                base = a.ring + static_cast<size_t>(slot) * plane + chan_off;
             } else {
-                base = a.in + static_cast<size_t>(q) * plane;
+                base = a.in + static_cast<size_t>(q) * plane + chan_off;
             }
-            v = *reinterpret_cast<const float2*>(base + chan_off + off);
         }
-        xr[m] = v.x;
-        xi[m] = v.y;
+        cb[i] = base;
+    }
+
+    float xr[P], xi[P];
+    switch ((t0 & (N - 1)) >> (LOGN - 2)) {  // window phase within its first chunk, in quarter chunks
+        case 0: load_window<PL, FN, 0>(cb, xr, xi); break;
+        case 1: load_window<PL, FN, 1>(cb, xr, xi); break;
+        case 2: load_window<PL, FN, 2>(cb, xr, xi); break;
+        default: load_window<PL, FN, 3>(cb, xr, xi); break;
     }
 
     const int ja = tid;
@@ -424,18 +469,26 @@ __global__ __launch_bounds__(PL::T* CPB) void fftconv_kernel(const KernelArgs a)
     spectrum_stage<PL>(xr, xi, a.pair, a.pair0, tid);
     run_passes<PL, true, 0>(xi, xr, lds, a.tw, tid, ja, jb);  // inverse = forward on swapped parts
 
-    const int total = a.n_steps << a.logN;
+    // kept samples: circular indices [j0, j0 + keep) -> registers m_lo <= m < m_hi; register m holds
+    // output-time o - j0 + 2T*m.  s = o - j0 may be negative: split into chunk part and phase.
+    const int total = a.n_steps << LOGN;
+    const int keep = (total - o) < a.V ? (total - o) : a.V;
+    const int m_lo = a.j0 / (2 * T), m_hi = (a.j0 + keep) / (2 * T);
+    const int s = o - a.j0;
+    const int k0 = s >> LOGN;  // floor
+    float* ob[FN + 1];
 #pragma unroll
-    for (int m = 0; m < P; ++m) {
-        const int rel = 2 * T * m - a.j0;  // wave-uniform
-        if (rel >= 0 && rel < a.V) {
-            const int tau = o + rel;
-            if (chan_ok && tau < total) {
-                const int k = tau >> a.logN;
-                const int off = tau & (N - 1);
-                float* dst = a.out + static_cast<size_t>(k) * plane + chan_off + off;
-                *reinterpret_cast<float2*>(dst) = make_float2(xr[m], xi[m]);
-            }
+    for (int i = 0; i < FN + 1; ++i) {
+        int k = k0 + i;
+        k = k < 0 ? 0 : (k < a.n_steps ? k : a.n_steps - 1);  // clamped ones are never stored to
+        ob[i] = a.out + static_cast<size_t>(k) * plane + chan_off;
+    }
+    if (chan_ok) {
+        switch ((s & (N - 1)) >> (LOGN - 2)) {
+            case 0: store_kept<PL, FN, 0>(ob, xr, xi, m_lo, m_hi); break;
+            case 1: store_kept<PL, FN, 1>(ob, xr, xi, m_lo, m_hi); break;
+            case 2: store_kept<PL, FN, 2>(ob, xr, xi, m_lo, m_hi); break;
+            default: store_kept<PL, FN, 3>(ob, xr, xi, m_lo, m_hi); break;
         }
     }
 }
