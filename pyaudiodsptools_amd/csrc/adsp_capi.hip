@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -86,7 +87,20 @@ const PlanInfo kPlans[] = {
     make_plan<Plan<16384, 32, 4, 32, 2, 16, 16>, 1, 4>(),
 };
 
+// experimental alternatives, selected with ADSP_PLAN_VARIANT=<n> (tuning only; index into this table)
+const PlanInfo kVariants[] = {
+    make_plan<Plan<4096, 16, 4, 16, 4, 8, 8>, 1, 2>(),   // 0
+    make_plan<Plan<4096, 16, 4, 16, 16, 2, 8>, 1, 2>(),  // 1
+    make_plan<Plan<4096, 16, 4, 8, 8, 8, 8>, 1, 2>(),    // 2
+    make_plan<Plan<4096, 16, 4, 4, 16, 8, 8>, 1, 2>(),   // 3
+};
+
 const PlanInfo* find_plan(int M, int FN) {
+    if (const char* v = getenv("ADSP_PLAN_VARIANT")) {
+        const int i = atoi(v);
+        if (i >= 0 && i < (int)(sizeof(kVariants) / sizeof(kVariants[0])) && kVariants[i].M == M && kVariants[i].FN == FN)
+            return &kVariants[i];
+    }
     for (const PlanInfo& p : kPlans)
         if (p.M == M && p.FN == FN) return &p;
     return nullptr;
@@ -109,17 +123,23 @@ int check_geometry(int N, int F, const PlanInfo** out) {
 }
 
 // forward-sign twiddles for passes 1.. of the forward then the inverse radix order
-void build_twiddles(const PlanInfo& pl, std::vector<float2>& tw) {
+// float4 entries (w_{2h+1}, w_{2h+2}) indexed [h * S + jlo], h < R/2; the last one's second half is unused
+void build_twiddles(const PlanInfo& pl, std::vector<float4>& tw) {
     tw.clear();
+    auto tw1 = [](int q, int jlo, int R, int S) {
+        const double ang = -2.0 * M_PI * (double)q * (double)jlo / ((double)R * (double)S);
+        return make_float2((float)std::cos(ang), (float)std::sin(ang));
+    };
     for (int dir = 0; dir < 2; ++dir) {
         int S = 1;
         for (int p = 0; p < pl.NP; ++p) {
             const int R = dir == 0 ? pl.rad[p] : pl.rad[pl.NP - 1 - p];
             if (p > 0) {
-                for (int q = 1; q < R; ++q)
+                for (int h = 0; h < R / 2; ++h)
                     for (int jlo = 0; jlo < S; ++jlo) {
-                        const double ang = -2.0 * M_PI * (double)q * (double)jlo / ((double)R * (double)S);
-                        tw.push_back(make_float2((float)std::cos(ang), (float)std::sin(ang)));
+                        const float2 a = tw1(2 * h + 1, jlo, R, S);
+                        const float2 b = (2 * h + 2 < R) ? tw1(2 * h + 2, jlo, R, S) : make_float2(1.f, 0.f);
+                        tw.push_back(make_float4(a.x, a.y, b.x, b.y));
                     }
             }
             S *= R;
@@ -151,8 +171,8 @@ struct adsp_engine {
     int M, logN, block_outputs;
     float* ring;   // [ring_slots][C][N]
     int ring_pos;  // slot of the most recent chunk
-    float2* tw;
-    float2* pair;
+    float4* tw;
+    float4* pair;
     float2* pair0;
     float* zeros;  // chunk_size zero floats
     bool have_spectrum;
@@ -172,13 +192,15 @@ int set_device(const adsp_engine* e) {
 int upload_pairs(adsp_engine* e, const float* H, hipStream_t stream) {
     const PlanInfo& pl = *e->plan;
     const int M = e->M, T = pl.T, R = pl.P / 2;
-    std::vector<float2> tab((size_t)R * 3 * T, make_float2(0.f, 0.f));
-    for (int r = 0; r < R; ++r)
+    // float4 layout [h][3][T]: (wc,g1) of pair 2h, (g2 of 2h, wc of 2h+1), (g1,g2) of 2h+1
+    std::vector<float4> tab((size_t)(R / 2) * 3 * T, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int h = 0; h < R / 2; ++h)
         for (int tid = 1; tid < T; ++tid) {
-            const PairEntry pe = pair_entry(H, M, tid + 2 * T * r);
-            tab[(size_t)(r * 3 + 0) * T + tid] = pe.wc;
-            tab[(size_t)(r * 3 + 1) * T + tid] = pe.g1;
-            tab[(size_t)(r * 3 + 2) * T + tid] = pe.g2;
+            const PairEntry a = pair_entry(H, M, tid + 2 * T * (2 * h));
+            const PairEntry b = pair_entry(H, M, tid + 2 * T * (2 * h + 1));
+            tab[(size_t)(h * 3 + 0) * T + tid] = make_float4(a.wc.x, a.wc.y, a.g1.x, a.g1.y);
+            tab[(size_t)(h * 3 + 1) * T + tid] = make_float4(a.g2.x, a.g2.y, b.wc.x, b.wc.y);
+            tab[(size_t)(h * 3 + 2) * T + tid] = make_float4(b.g1.x, b.g1.y, b.g2.x, b.g2.y);
         }
     std::vector<float2> tab0((size_t)(R + 1) * 3);
     auto put0 = [&](int idx, int k) {
@@ -193,7 +215,7 @@ int upload_pairs(adsp_engine* e, const float* H, hipStream_t stream) {
     for (int r = 0; r < R / 2; ++r) put0(2 + (R / 2 - 1) + r, T + 2 * T * r);
     // synchronous copies from pageable memory: safe to free the vectors on return
     HIP_TRY(hipStreamSynchronize(stream));
-    HIP_TRY(hipMemcpy(e->pair, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->pair, tab.data(), tab.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->pair0, tab0.data(), tab0.size() * sizeof(float2), hipMemcpyHostToDevice));
     e->have_spectrum = true;
     return ADSP_OK;
@@ -297,7 +319,9 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     e->block_outputs = N;
     e->ring = nullptr;
     e->ring_pos = slots - 1;
-    e->tw = e->pair = e->pair0 = nullptr;
+    e->tw = nullptr;
+    e->pair = nullptr;
+    e->pair0 = nullptr;
     e->zeros = nullptr;
     e->have_spectrum = false;
     e->stage_in = e->stage_out = nullptr;
@@ -313,15 +337,15 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     const size_t ring_bytes = (size_t)slots * e->plane() * sizeof(float);
     if ((err = hipMalloc(&e->ring, ring_bytes)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc ring (%zu bytes): %s", ring_bytes, hipGetErrorString(err)));
     if ((err = hipMemset(e->ring, 0, ring_bytes)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMemset: %s", hipGetErrorString(err)));
-    std::vector<float2> tw;
+    std::vector<float4> tw;
     build_twiddles(*pl, tw);
     if ((int)tw.size() != pl->tw_total) return bail(fail(ADSP_ERR_STATE, "internal: twiddle count %zu != %d", tw.size(), pl->tw_total));
-    const size_t tw_bytes = (tw.size() + 1) * sizeof(float2);
+    const size_t tw_bytes = (tw.size() + 1) * sizeof(float4);
     if ((err = hipMalloc(&e->tw, tw_bytes)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
-    if (!tw.empty() && (err = hipMemcpy(e->tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice)) != hipSuccess)
+    if (!tw.empty() && (err = hipMemcpy(e->tw, tw.data(), tw.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess)
         return bail(fail(ADSP_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(err)));
     const int R = pl->P / 2;
-    if ((err = hipMalloc(&e->pair, (size_t)R * 3 * pl->T * sizeof(float2))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
+    if ((err = hipMalloc(&e->pair, (size_t)(R / 2) * 3 * pl->T * sizeof(float4))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
     if ((err = hipMalloc(&e->pair0, (size_t)(R + 1) * 3 * sizeof(float2))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
     if ((err = hipMalloc(&e->zeros, (size_t)N * sizeof(float))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
     if ((err = hipMemset(e->zeros, 0, (size_t)N * sizeof(float))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMemset: %s", hipGetErrorString(err)));

@@ -31,14 +31,21 @@
 #include <hip/hip_runtime.h>
 #include <utility>
 
+// ADSP_ABLATE: tuning-only bitmask that removes one ingredient of the kernel to see what it costs
+// (results are then wrong).  1: pass twiddles not loaded  2: pair tables not loaded  4: no LDS exchange
+// 8: no global input loads  16: no output stores  32: butterflies replaced by copies.  Never set in product builds.
+#ifndef ADSP_ABLATE
+#define ADSP_ABLATE 0
+#endif
+
 namespace adsp {
 
 struct KernelArgs {
     const float* ring;     // [ring_slots][C][N] input history ring
     const float* in;       // [n_steps][C][N] new input (may point into the ring)
     float* out;            // [n_steps][C][N]
-    const float2* tw;      // pass twiddles: forward passes 1.., then inverse passes 1..
-    const float2* pair;    // [R][3][T]  (wc', g1, g2) for threads 1..T-1
+    const float4* tw;      // pass twiddles as (w_odd, w_even) pairs: forward passes 1.., then inverse passes 1..
+    const float4* pair;    // [R/2][3][T] float4: (wc,g1)_r, (g2_r,wc_r+1), (g1,g2)_r+1 for threads 1..T-1
     const float2* pair0;   // [R+1][3]   thread 0's self-paired butterflies
     const float* zeros;    // >= N zero floats (stands in for chunks that do not exist)
     int ring_pos;          // slot holding the most recent history chunk (time step -1)
@@ -67,14 +74,16 @@ struct Plan {
         for (int i = 0; i < p; ++i) s *= rad(inverse, i);
         return s;
     }
+    // twiddles are stored as float4 = (w_{2p+1}, w_{2p+2}), p < R/2, per j_lo: R/2 * S float4 per pass
+    // (one 16-byte load costs the TA exactly what an 8-byte one does: ~16 cycles per wave instruction)
     static constexpr int tw_count(bool inverse) {
         int n = 0;
-        for (int p = 1; p < NP_; ++p) n += (rad(inverse, p) - 1) * stride(inverse, p);
+        for (int p = 1; p < NP_; ++p) n += (rad(inverse, p) / 2) * stride(inverse, p);
         return n;
     }
     static constexpr int tw_offset(bool inverse, int p) {
         int n = inverse ? tw_count(false) : 0;
-        for (int i = 1; i < p; ++i) n += (rad(inverse, i) - 1) * stride(inverse, i);
+        for (int i = 1; i < p; ++i) n += (rad(inverse, i) / 2) * stride(inverse, i);
         return n;
     }
     static constexpr int tw_total = tw_count(false) + tw_count(true);
@@ -96,6 +105,9 @@ __device__ constexpr float kCos32[9] = {1.0f,
                                         0.19509032201612826785f,
                                         0.0f};
 
+// cos(2*pi*i/32) for 0 <= i <= 16
+__device__ constexpr float cos32(int i) { return i <= 8 ? kCos32[i < 0 ? 0 : i] : -kCos32[i > 16 ? 0 : 16 - i]; }
+
 // t = W32^IDX * o,  W32 = exp(-2*pi*i/32),  0 <= IDX < 16
 template <int IDX>
 __device__ __forceinline__ void twmul32(float o_r, float o_i, float& t_r, float& t_i) {
@@ -113,8 +125,8 @@ __device__ __forceinline__ void twmul32(float o_r, float o_i, float& t_r, float&
         t_r = (o_i - o_r) * kCos32[4];
         t_i = -(o_r + o_i) * kCos32[4];
     } else {
-        constexpr float wr = IDX <= 8 ? kCos32[IDX] : -kCos32[16 - IDX];
-        constexpr float wi = -(IDX <= 8 ? kCos32[8 - IDX] : kCos32[IDX - 8]);
+        constexpr float wr = cos32(IDX);
+        constexpr float wi = -cos32(IDX <= 8 ? 8 - IDX : IDX - 8);  // -sin(2 pi IDX / 32)
         t_r = o_r * wr - o_i * wi;
         t_i = o_r * wi + o_i * wr;
     }
@@ -213,7 +225,7 @@ struct Pass {
         return tid + T * i;
     }
 
-    static __device__ __forceinline__ void compute(float (&ar)[P], float (&ai)[P], const float2* __restrict__ tw,
+    static __device__ __forceinline__ void compute(float (&ar)[P], float (&ai)[P], const float4* __restrict__ tw,
                                                    int tid, int ja, int jb) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -226,14 +238,30 @@ struct Pass {
             if constexpr (S > 1) {
                 const int jlo = bfly(i, tid, ja, jb) & (S - 1);
 #pragma unroll
-                for (int q = 1; q < R; ++q) {
-                    const float2 w = tw[TWOFF + (q - 1) * S + jlo];
-                    const float xr = ur[q], xi = ui[q];
-                    ur[q] = xr * w.x - xi * w.y;
-                    ui[q] = xr * w.y + xi * w.x;
+                for (int h = 0; h < R / 2; ++h) {
+#if ADSP_ABLATE & 1
+                    const float4 w = tw[TWOFF + (jlo & 1)];
+#else
+                    const float4 w = tw[TWOFF + h * S + jlo];
+#endif
+                    {
+                        const float xr = ur[2 * h + 1], xi = ui[2 * h + 1];
+                        ur[2 * h + 1] = xr * w.x - xi * w.y;
+                        ui[2 * h + 1] = xr * w.y + xi * w.x;
+                    }
+                    if (2 * h + 2 < R) {
+                        const float xr = ur[2 * h + 2], xi = ui[2 * h + 2];
+                        ur[2 * h + 2] = xr * w.z - xi * w.w;
+                        ui[2 * h + 2] = xr * w.w + xi * w.z;
+                    }
                 }
             }
+#if ADSP_ABLATE & 32
+#pragma unroll
+            for (int r = 0; r < R; ++r) { vr[r] = ur[r]; vi[r] = ui[r]; }
+#else
             Dft<R>::run(ur, ui, vr, vi);
+#endif
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 ar[i + r * NB] = vr[r];
@@ -286,14 +314,16 @@ struct Pass {
 
 template <class PL, bool INV, int p>
 __device__ __forceinline__ void run_passes(float (&ar)[PL::P], float (&ai)[PL::P], float2* lds,
-                                           const float2* __restrict__ tw, int tid, int ja, int jb) {
+                                           const float4* __restrict__ tw, int tid, int ja, int jb) {
     using PS = Pass<PL, INV, p>;
     PS::compute(ar, ai, tw, tid, ja, jb);
     if constexpr (!PS::LAST) {
+#if !(ADSP_ABLATE & 4)
         if constexpr (INV || p > 0) __syncthreads();  // everyone is done reading the previous exchange
         PS::write(ar, ai, lds, tid, ja, jb);
         __syncthreads();
         PS::read(ar, ai, lds, tid, ja, jb);
+#endif
         run_passes<PL, INV, p + 1>(ar, ai, lds, tw, tid, ja, jb);
     }
 }
@@ -323,18 +353,26 @@ __device__ __forceinline__ void pair_op(float& zar, float& zai, float& zbr, floa
 
 template <class PL>
 __device__ __forceinline__ void spectrum_stage(float (&xr)[PL::P], float (&xi)[PL::P],
-                                               const float2* __restrict__ pair, const float2* __restrict__ pair0,
+                                               const float4* __restrict__ pair, const float2* __restrict__ pair0,
                                                int tid) {
     constexpr int R = PL::RL, T = PL::T;
     // registers: butterfly a (j = ja) output r -> [2r];  butterfly b (j = jb) output r -> [2r+1]
     if (tid != 0) {
-        // k = tid + 2T*r pairs with M-k = jb + 2T*(R-1-r)
+        // k = tid + 2T*r pairs with M-k = jb + 2T*(R-1-r); two pairs share three 16-byte table loads
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const float2 wc = pair[(r * 3 + 0) * T + tid];
-            const float2 g1 = pair[(r * 3 + 1) * T + tid];
-            const float2 g2 = pair[(r * 3 + 2) * T + tid];
-            pair_op(xr[2 * r], xi[2 * r], xr[2 * (R - 1 - r) + 1], xi[2 * (R - 1 - r) + 1], wc, g1, g2);
+        for (int h = 0; h < R / 2; ++h) {
+#if ADSP_ABLATE & 2
+            const float4 f0 = pair[(tid & 1)], f1 = pair[T + (tid & 1)], f2 = pair[2 * T + (tid & 1)];
+#else
+            const float4 f0 = pair[(h * 3 + 0) * T + tid];
+            const float4 f1 = pair[(h * 3 + 1) * T + tid];
+            const float4 f2 = pair[(h * 3 + 2) * T + tid];
+#endif
+            const int r0 = 2 * h, r1 = 2 * h + 1;
+            pair_op(xr[2 * r0], xi[2 * r0], xr[2 * (R - 1 - r0) + 1], xi[2 * (R - 1 - r0) + 1], make_float2(f0.x, f0.y),
+                    make_float2(f0.z, f0.w), make_float2(f1.x, f1.y));
+            pair_op(xr[2 * r1], xi[2 * r1], xr[2 * (R - 1 - r1) + 1], xi[2 * (R - 1 - r1) + 1], make_float2(f1.z, f1.w),
+                    make_float2(f2.x, f2.y), make_float2(f2.z, f2.w));
         }
     } else {
         // thread 0 owns the two self-paired butterflies j = 0 and j = T.
@@ -379,7 +417,11 @@ __device__ __forceinline__ void load_window(const float* const (&cb)[FN + 1], fl
         const int gi = RQ * Q + m;
         const int i = gi / MPC;
         const int off = (gi % MPC) * 2 * T;
+#if ADSP_ABLATE & 8
+        const float2 v = make_float2(static_cast<float>(off + i) * 1e-4f, reinterpret_cast<size_t>(cb[i]) * 1e-20f);
+#else
         const float2 v = *reinterpret_cast<const float2*>(cb[i] + off);
+#endif
         xr[m] = v.x;
         xi[m] = v.y;
     }
@@ -395,7 +437,11 @@ __device__ __forceinline__ void store_kept(float* const (&ob)[FN + 1], const flo
             const int gi = RQ * Q + m;
             const int i = gi / MPC;
             const int off = (gi % MPC) * 2 * T;
+#if ADSP_ABLATE & 16
+            if (xr[m] == 123.456f) *reinterpret_cast<float2*>(ob[i] + off) = make_float2(xr[m], xi[m]);
+#else
             *reinterpret_cast<float2*>(ob[i] + off) = make_float2(xr[m], xi[m]);
+#endif
         }
     }
 }
