@@ -4,16 +4,24 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 Workload (BASELINE.json configs[1]): CreateLowCutFilter(800) @ 44.1 kHz on 4096 mono channels x
-4096-sample chunks per GPU, float32, synthetic uniform(-1,1) input already resident in HBM.  A
-"step" filters one [channels, chunk] batch (one chunk per channel, the reference's one apply() per
-device), through the zero-copy streaming entry point (adsp_ring_acquire / adsp_apply_ring): one
-kernel launch per step.  For N > 1 (torchrun, one rank per GPU) every rank owns its own channel
-shard (weak scaling); the only collective is the RCCL broadcast of the filter spectrum before the
-timed region.
+4096-sample chunks per GPU, float32, synthetic uniform(-1,1) input already resident in HBM.
 
-Prints ONE JSON line on rank 0 (see the driver contract) including
-  roofline     - algorithmic bytes (8 B/sample) / average kernel launch duration vs 8 TB/s
-  cpu_baseline - the oracle's literal restatement of the reference (numpy, 1 core) on a bounded sample.
+A "step" filters one [channels, chunk] batch (one chunk per channel = one reference apply() per
+device).  Default mode "batch": the K steps' inputs sit in HBM as [steps, channels, chunk] arrays
+and are handed to adsp_apply_device `--steps-per-launch` steps at a time (many chunks of every
+channel batched as one grid; each 2N transform then keeps 1.5 N samples).  `--mode stream` runs one
+launch per step through the zero-copy ring (adsp_apply_ring), the real-time call pattern; its
+figure is also measured (after the timed region) and reported under "stream" in the same line.
+History is carried by the engine exactly as between reference apply() calls; every output sample of
+every step is produced inside the timed region.
+
+For N > 1 (torchrun, one rank per GPU) every rank owns its own channel shard (weak scaling); the
+only collective is the RCCL broadcast of the filter spectrum before the timed region.
+
+Prints ONE JSON line on rank 0 (driver contract) including
+  roofline     - algorithmic bytes (8 B/sample) / average KERNEL duration (HIP events around each
+                 kernel launch on the launch stream, adsp_kernel_time) vs the 8 TB/s HBM3E spec
+  cpu_baseline - the oracle's literal restatement of the reference (numpy, 1 core), bounded sample.
 """
 import argparse
 import json
@@ -26,26 +34,35 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 ALG_BYTES_PER_SAMPLE = 8  # 4 B read + 4 B written, SURVEY.md 8(d)
+
+FILTER_NAMES = {"lowcut": "CreateLowCutFilter(800)", "highcut": "CreateHighCutFilter(8000)",
+                "eq3": "CreateEQ3BandFFT(100,2,700,-4,8000,5)",
+                "chain": "LowCut(800)->EQ3BandFFT(100,2,700,-4,8000,5)->HighCut(8000) fused"}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--channels", type=int, default=4096, help="channels PER GPU")
     ap.add_argument("--chunk", type=int, default=4096)
     ap.add_argument("--fs", type=int, default=44100)
-    ap.add_argument("--filter", default="lowcut", choices=["lowcut", "highcut", "eq3", "chain"])
-    ap.add_argument("--mode", default="stream", choices=["stream", "offline"],
-                    help="stream: one launch per step (zero-copy ring). offline: --steps-per-launch steps per launch")
-    ap.add_argument("--steps-per-launch", type=int, default=16)
+    ap.add_argument("--filter", default="lowcut", choices=sorted(FILTER_NAMES))
+    ap.add_argument("--mode", default="batch", choices=["batch", "offline", "stream"],
+                    help="batch (= offline): --steps-per-launch steps per launch; stream: one launch per step, zero-copy ring")
+    ap.add_argument("--steps-per-launch", type=int, default=32)
     ap.add_argument("--ring-slots", type=int, default=8)
+    ap.add_argument("--fft-mult", type=int, default=0, help="force transform length = this multiple of the chunk (0 = smallest)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stream-extra", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.mode == "offline":
+        a.mode = "batch"
+    return a
 
 
 def make_fir(args):
@@ -68,7 +85,8 @@ def cpu_baseline(args):
     elif args.filter == "eq3":
         dev = orc.OracleEQ3BandFFT(100, 2, 700, -4, 8000, 5, fs, n)
     else:
-        a, b, c = orc.OracleLowCut(800, fs, n), orc.OracleEQ3BandFFT(100, 2, 700, -4, 8000, 5, fs, n), orc.OracleHighCut(8000, fs, n)
+        a, b, c = (orc.OracleLowCut(800, fs, n), orc.OracleEQ3BandFFT(100, 2, 700, -4, 8000, 5, fs, n),
+                   orc.OracleHighCut(8000, fs, n))
 
         class _Chain:
             def apply(self, x):
@@ -92,6 +110,76 @@ def cpu_baseline(args):
                       f"(oracle restatement of the reference's apply), {el:.1f} s on 1 of {os.cpu_count()} host cores"}
 
 
+class Runner:
+    """One measured configuration: engine + resident synthetic data + a run(k_steps) closure."""
+
+    def __init__(self, args, mode, fir, dev, local_rank, world, rank):
+        import torch
+        from pyaudiodsptools_amd import dist as adist
+        self.torch = torch
+        self.mode = mode
+        C, N = args.channels, args.chunk
+        self.C, self.N = C, N
+        stream_mode = mode == "stream"
+        self.bank = adist.ShardedFirBank(fir, C * world, device=local_rank,
+                                         ring_slots=args.ring_slots if stream_mode else 0, fft_mult=args.fft_mult)
+        self.eng = eng = self.bank.engine
+        assert eng.channels == C
+        self.stream = torch.cuda.current_stream(dev)
+        sptr = self.stream.cuda_stream
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1234 + rank)
+        if stream_mode:
+            # zero-copy streaming: the synthetic producer has filled every ring slot before the timed region
+            # (apply_device copies each batch into the ring and advances it; setup only)
+            scratch = torch.empty((C, N), device=dev, dtype=torch.float32)
+            for _ in range(eng.ring_slots):
+                batch = torch.empty((C, N), device=dev, dtype=torch.float32).uniform_(-1, 1, generator=gen)
+                eng.apply_device(batch, scratch, 1, sptr)
+                torch.cuda.synchronize(dev)
+            self.outs = [torch.empty((C, N), device=dev, dtype=torch.float32) for _ in range(4)]
+            self.spl = 1
+
+            def run(k_steps):
+                for i in range(k_steps):
+                    eng.apply_ring(self.outs[i % 4], sptr)
+        else:
+            self.spl = spl = args.steps_per_launch
+            # distinct resident input batches, > 256 MiB in total so the Infinity Cache cannot hold them
+            n_in = max(2, min(8, -(-(768 << 20) // (spl * C * N * 4))))
+            self.ins = [torch.empty((spl, C, N), device=dev, dtype=torch.float32).uniform_(-1, 1, generator=gen)
+                        for _ in range(n_in)]
+            self.outs = [torch.empty((spl, C, N), device=dev, dtype=torch.float32) for _ in range(2)]
+
+            def run(k_steps):
+                for i in range(k_steps // spl):
+                    eng.apply_device(self.ins[i % n_in], self.outs[i % 2], spl, sptr)
+        self.run = run
+
+    def measure(self, steps, warm, barrier=None):
+        torch, eng = self.torch, self.eng
+        steps = max(self.spl, (steps // self.spl) * self.spl)
+        warm = -(-warm // self.spl) * self.spl if warm else 0
+        self.run(warm)
+        torch.cuda.synchronize()
+        if barrier:
+            barrier()
+        torch.cuda.synchronize()
+        eng.enable_kernel_timing(True)
+        t0 = time.perf_counter()
+        self.run(steps)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        if barrier:
+            barrier()
+        torch.cuda.synchronize()
+        kern_ms, launches = eng.kernel_time()
+        eng.enable_kernel_timing(False)
+        chk = self.outs[0].reshape(-1)[:: max(1, self.outs[0].numel() // 65536)]
+        assert bool(torch.isfinite(chk).all()) and float(chk.abs().max()) > 0
+        return steps, warm, wall, kern_ms, launches
+
+
 def main():
     args = parse()
     import torch
@@ -107,93 +195,51 @@ def main():
         raise SystemExit("bench.py needs a GPU (pyaudiodsptools_amd has no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    barrier = None
     if world > 1:
         adist.init_process_group("nccl")
         import torch.distributed as tdist
+        barrier = tdist.barrier
 
     fir = make_fir(args)
     C, N = args.channels, args.chunk
-    offline = args.mode == "offline"
-    bank = adist.ShardedFirBank(fir, C * world, device=local_rank, ring_slots=0 if offline else args.ring_slots)
-    eng = bank.engine
-    assert eng.channels == C
-    stream = torch.cuda.current_stream(dev)
-    sptr = stream.cuda_stream
-
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    n_out_bufs = 4
-    if offline:
-        spl = args.steps_per_launch
-        # resident input: enough distinct launches' worth of chunks to defeat the 256 MiB Infinity Cache
-        n_in = max(2, min(8, (1 << 30) // (spl * C * N * 4)))
-        ins = [torch.empty((spl, C, N), device=dev, dtype=torch.float32).uniform_(-1, 1, generator=gen) for _ in range(n_in)]
-        outs = [torch.empty((spl, C, N), device=dev, dtype=torch.float32) for _ in range(2)]
-        steps = (args.steps // spl) * spl or spl
-        warm = -(-args.warmup // spl) * spl if args.warmup else 0
-
-        def run(k_steps):
-            for i in range(k_steps // spl):
-                eng.apply_device(ins[i % n_in], outs[i % 2], spl, sptr)
-        launches = steps // spl
-    else:
-        # zero-copy streaming: the synthetic producer has already filled every ring slot
-        # (apply_device copies each new batch into the ring and advances it; setup, untimed)
-        scratch = torch.empty((C, N), device=dev, dtype=torch.float32)
-        for _ in range(eng.ring_slots):
-            batch = torch.empty((C, N), device=dev, dtype=torch.float32).uniform_(-1, 1, generator=gen)
-            eng.apply_device(batch, scratch, 1, sptr)
-            torch.cuda.synchronize(dev)
-        outs = [torch.empty((C, N), device=dev, dtype=torch.float32) for _ in range(n_out_bufs)]
-        steps, warm = args.steps, args.warmup
-
-        def run(k_steps):
-            for i in range(k_steps):
-                eng.apply_ring(outs[i % n_out_bufs], sptr)
-        launches = steps
-
-    run(warm)
-    torch.cuda.synchronize(dev)
+    main_run = Runner(args, args.mode, fir, dev, local_rank, world, rank)
+    steps, warm, wall, kern_ms, launches = main_run.measure(args.steps, args.warmup, barrier)
     if world > 1:
-        tdist.barrier()
-    torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    run(steps)
-    ev1.record(stream)
-    torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
-    if world > 1:
-        tdist.barrier()
-    torch.cuda.synchronize(dev)
-    gpu_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        t = torch.tensor([wall, gpu_ms], device=dev, dtype=torch.float64)
+        t = torch.tensor([wall, kern_ms], device=dev, dtype=torch.float64)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
-        wall, gpu_ms = float(t[0]), float(t[1])
+        wall, kern_ms = float(t[0]), float(t[1])
 
-    # sanity: outputs are finite and non-trivial
-    chk = outs[0].reshape(-1)[:: max(1, outs[0].numel() // 65536)]
-    assert bool(torch.isfinite(chk).all()) and float(chk.abs().max()) > 0
+    extra_stream = None
+    if args.mode != "stream" and not args.no_stream_extra and world == 1:
+        del main_run.ins
+        torch.cuda.empty_cache()
+        s_run = Runner(args, "stream", fir, dev, local_rank, world, rank)
+        s_steps, _, s_wall, s_kern_ms, s_launches = s_run.measure(128, 16)
+        s_per = s_kern_ms / 1e3 / s_launches
+        extra_stream = {"value": round(C * N * s_steps / s_wall / 1e6, 1), "unit": "Msamples/s", "steps": s_steps,
+                        "avg_kernel_us": round(s_per * 1e6, 2),
+                        "roofline_frac": round(ALG_BYTES_PER_SAMPLE * C * N / s_per / 1e9 / HBM_PEAK_GBS, 4),
+                        "note": "one launch per step through the zero-copy ring (adsp_apply_ring), N outputs kept per 2N transform"}
 
     if rank == 0:
-        samples_per_step = C * N * world
-        value = samples_per_step * steps / wall / 1e6
-        per_launch_s = gpu_ms / 1e3 / launches
+        eng = main_run.eng
+        value = C * N * world * steps / wall / 1e6
+        per_launch_s = kern_ms / 1e3 / launches
         samples_per_launch = C * N * (steps // launches)
         achieved = ALG_BYTES_PER_SAMPLE * samples_per_launch / per_launch_s / 1e9
+        mode_key = "stream" if args.mode == "stream" else "batch"
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
-                rec = json.load(open(tf)).get(f"{args.filter}_{C}x{N}_{args.mode}")
-                if rec:
-                    traffic = rec
+                rec = json.load(open(tf)).get(f"{args.filter}_{C}x{N}_{mode_key}")
+                if rec and rec.get("steps_per_launch", main_run.spl) == main_run.spl:
+                    traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
-            "metric": "Msamples/s (float32, 4096-pt OLA FFT filter)" if N == 4096 else f"Msamples/s (float32, {N}-pt OLA FFT filter)",
+            "metric": f"Msamples/s (float32, {N}-pt OLA FFT filter)",
             "value": round(value, 1),
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -204,19 +250,20 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic uniform(-1,1) float32, resident in HBM (library input ring)" if not offline else
-                    "synthetic uniform(-1,1) float32, resident in HBM ([steps, C, N] batches)",
-            "config": {"workload": f"Create{ {'lowcut':'LowCutFilter(800)','highcut':'HighCutFilter(8000)','eq3':'EQ3BandFFT(100,2,700,-4,8000,5)','chain':'LowCut(800)->EQ3BandFFT->HighCut(8000) fused'}[args.filter]} "
-                                   f"@ {args.fs} Hz, {C} mono channels x {N}-sample chunks per GPU",
-                       "channels_per_gpu": C, "chunk_size": N, "mode": args.mode,
-                       "steps_per_launch": (args.steps_per_launch if offline else 1),
-                       "fft_size": eng.geometry.fft_size, "outputs_per_transform": (eng.block_outputs if offline else N),
+            "data": "synthetic uniform(-1,1) float32 resident in HBM " +
+                    ("(library input ring)" if args.mode == "stream" else "([steps, channels, chunk] batches)"),
+            "config": {"workload": f"{FILTER_NAMES[args.filter]} @ {args.fs} Hz, {C} mono channels x {N}-sample chunks per GPU",
+                       "channels_per_gpu": C, "chunk_size": N, "mode": mode_key, "steps_per_launch": main_run.spl,
+                       "fft_size": eng.geometry.fft_size,
+                       "outputs_per_transform": (N if args.mode == "stream" else eng.block_outputs),
                        "parallelism": f"channel-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "fftconv_kernel", "avg_launch_us": round(per_launch_s * 1e6, 2),
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * samples_per_launch},
+                         "kernel": "adsp::fftconv_kernel", "avg_launch_us": round(per_launch_s * 1e6, 2),
+                         "launches": launches, "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * samples_per_launch},
         }
+        if extra_stream:
+            line["stream"] = extra_stream
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), flush=True)

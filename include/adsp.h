@@ -134,6 +134,13 @@ ADSP_API int adsp_apply_ring(adsp_engine* engine, float* d_out, void* stream);
 ADSP_API int adsp_get_state(adsp_engine* engine, float* host_history);
 ADSP_API int adsp_set_state(adsp_engine* engine, const float* host_history);
 
+/* Kernel timing for benchmarks: when enabled, every launch of the filter kernel is bracketed by a pair
+ * of HIP events recorded on the launch stream (the kernel only - not the history copy that follows a
+ * multi-step launch).  adsp_kernel_time synchronises those events, returns the summed kernel time in
+ * milliseconds and the number of launches since the last call, and clears the record. */
+ADSP_API int adsp_enable_kernel_timing(adsp_engine* engine, int enable);
+ADSP_API int adsp_kernel_time(adsp_engine* engine, double* total_ms, int* launches);
+
 /* Block until everything this engine enqueued on `stream` is done. */
 ADSP_API int adsp_synchronize(adsp_engine* engine, void* stream);
 

@@ -53,6 +53,8 @@ SIGNATURES = {
     "adsp_apply_ring": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_void_p]),
     "adsp_get_state": (ctypes.c_int, [_engine_p, ctypes.c_void_p]),
     "adsp_set_state": (ctypes.c_int, [_engine_p, ctypes.c_void_p]),
+    "adsp_enable_kernel_timing": (ctypes.c_int, [_engine_p, ctypes.c_int]),
+    "adsp_kernel_time": (ctypes.c_int, [_engine_p, ctypes.POINTER(ctypes.c_double), _c_int_p]),
     "adsp_synchronize": (ctypes.c_int, [_engine_p, ctypes.c_void_p]),
 }
 

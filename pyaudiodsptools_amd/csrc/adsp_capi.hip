@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/adsp.h"
@@ -179,6 +180,9 @@ struct adsp_engine {
     float* stage_in;
     float* stage_out;
     size_t stage_elems;
+    bool timing;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;   // recorded, not yet read
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_ev;  // recycled event pairs
     size_t plane() const { return (size_t)cfg.n_channels * (size_t)cfg.chunk_size; }
 };
 
@@ -244,7 +248,22 @@ int launch(adsp_engine* e, const float* d_in, float* d_out, int n_steps, hipStre
     a.ncg = (c.n_channels + pl.CPB - 1) / pl.CPB;
     const long long grid = (long long)((a.ncg + 7) / 8) * 8 * a.nblk;
     if (grid > 0x7fffffffLL) return fail(ADSP_ERR_ARG, "launch too large (%lld workgroups)", grid);
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if (e->timing) {
+        if (!e->free_ev.empty()) {
+            ev = e->free_ev.back();
+            e->free_ev.pop_back();
+        } else {
+            HIP_TRY(hipEventCreate(&ev.first));
+            HIP_TRY(hipEventCreate(&ev.second));
+        }
+        HIP_TRY(hipEventRecord(ev.first, stream));
+    }
     HIP_TRY(pl.launch(a, (int)grid, stream));
+    if (e->timing) {
+        HIP_TRY(hipEventRecord(ev.second, stream));
+        e->timed.push_back(ev);
+    }
     return ADSP_OK;
 }
 
@@ -326,6 +345,7 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     e->have_spectrum = false;
     e->stage_in = e->stage_out = nullptr;
     e->stage_elems = 0;
+    e->timing = false;
 
     auto bail = [&](int code) {
         adsp_destroy(e);
@@ -364,6 +384,11 @@ int adsp_destroy(adsp_engine* e) {
     if (e->zeros) (void)hipFree(e->zeros);
     if (e->stage_in) (void)hipFree(e->stage_in);
     if (e->stage_out) (void)hipFree(e->stage_out);
+    for (auto& v : {&e->timed, &e->free_ev})
+        for (auto& p : *v) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
     delete e;
     return ADSP_OK;
 }
@@ -497,6 +522,30 @@ int adsp_set_state(adsp_engine* e, const float* host_history) {
         const int slot = ((e->ring_pos + 1 - nh + h) % S + S) % S;
         HIP_TRY(hipMemcpy(e->ring + (size_t)slot * plane, host_history + (size_t)h * plane, plane * sizeof(float), hipMemcpyHostToDevice));
     }
+    return ADSP_OK;
+}
+
+int adsp_enable_kernel_timing(adsp_engine* e, int enable) {
+    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    e->timing = enable != 0;
+    return ADSP_OK;
+}
+
+int adsp_kernel_time(adsp_engine* e, double* total_ms, int* launches) {
+    if (!e || !total_ms || !launches) return fail(ADSP_ERR_ARG, "NULL argument");
+    int rc = set_device(e);
+    if (rc) return rc;
+    double sum = 0.0;
+    for (auto& p : e->timed) {
+        HIP_TRY(hipEventSynchronize(p.second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = (int)e->timed.size();
+    e->free_ev.insert(e->free_ev.end(), e->timed.begin(), e->timed.end());
+    e->timed.clear();
     return ADSP_OK;
 }
 

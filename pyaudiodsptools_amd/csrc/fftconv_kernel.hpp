@@ -38,6 +38,10 @@
 #define ADSP_ABLATE 0
 #endif
 
+#ifndef ADSP_MIN_WAVES
+#define ADSP_MIN_WAVES 1
+#endif
+
 namespace adsp {
 
 struct KernelArgs {
@@ -450,7 +454,7 @@ __device__ __forceinline__ void store_kept(float* const (&ob)[FN + 1], const flo
 // the kernel: one workgroup = CPB channels x one time block
 // ------------------------------------------------------------------------------------------
 template <class PL, int CPB, int FN>
-__global__ __launch_bounds__(PL::T* CPB) void fftconv_kernel(const KernelArgs a) {
+__global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(const KernelArgs a) {
     constexpr int M = PL::M, P = PL::P, T = PL::T;
     constexpr int N = 2 * M / FN;  // chunk size
     constexpr int LOGN = __builtin_ctz(N);

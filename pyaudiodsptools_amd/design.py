@@ -109,13 +109,14 @@ class Geometry:
     max_block_outputs: int
 
 
-def overlap_save_geometry(fir: FirStream) -> Geometry:
+def overlap_save_geometry(fir: FirStream, fft_mult: int = 0) -> Geometry:
     """Choose F, the window position and the kept slice for the GPU engine (include/adsp.h).
 
     Output tau is y[tau - D] with y = taps (*) s and D = delay.  The window for the block starting at
     output-time o begins at input-time o - lookback, so output tau sits at circular index
     (tau - o) + lookback - D + shift; it is wrap-free when lookback >= D + len(taps) - 1.
     Everything is kept a multiple of N/4 (>= 2 * threads-per-transform for every plan).
+    fft_mult = 4 forces a 4N transform (fewer, larger blocks in multi-step launches).
     """
     n = int(fir.chunk_size)
     if n < 64 or n & (n - 1):
@@ -128,11 +129,11 @@ def overlap_save_geometry(fir: FirStream) -> Geometry:
     lookback = -(-(d_total + m - 1) // g) * g
     shift = (-(lookback - d_total)) % g
     out_offset = lookback - d_total + shift
-    for f in (2 * n, 4 * n):
+    for f in ((2 * n, 4 * n) if not fft_mult else (fft_mult * n,)):
         if out_offset + n <= f:
             break
     else:
-        raise ValueError(f"kernel of {m} taps does not fit a 4N transform at N={n}")
+        raise ValueError(f"kernel of {m} taps does not fit a {fft_mult or 4}N transform at N={n}")
     hist = -(-lookback // n)
     vmax = ((f - out_offset) // g) * g
     return Geometry(f, hist, lookback, out_offset, shift, vmax)

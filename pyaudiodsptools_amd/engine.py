@@ -26,11 +26,12 @@ def _ptr(x):
 
 
 class FirEngine:
-    def __init__(self, fir: FirStream, channels=1, device=0, ring_slots=0):
+    def __init__(self, fir: FirStream, channels=1, device=0, ring_slots=0, fft_mult=0):
         self._lib = _capi.load()
         self._h = ctypes.c_void_p(None)
         self.fir = fir
-        self.geometry = geo = overlap_save_geometry(fir)
+        self.fft_mult = int(fft_mult)
+        self.geometry = geo = overlap_save_geometry(fir, self.fft_mult)
         self.chunk_size = int(fir.chunk_size)
         self.channels = int(channels)
         self.device = int(device)
@@ -58,7 +59,7 @@ class FirEngine:
     # -- filter -------------------------------------------------------------------------------
     def set_fir(self, fir: FirStream):
         """Change the filter without touching the history (same geometry required)."""
-        geo = overlap_save_geometry(fir)
+        geo = overlap_save_geometry(fir, self.fft_mult)
         if geo != self.geometry:
             raise ValueError("new filter needs a different transform geometry; create a new engine")
         self.fir = fir
@@ -116,6 +117,15 @@ class FirEngine:
 
     def apply_ring(self, d_out, stream=None):
         _capi.check(self._lib.adsp_apply_ring(self._h, _ptr(d_out), _ptr(stream)))
+
+    def enable_kernel_timing(self, enable=True):
+        _capi.check(self._lib.adsp_enable_kernel_timing(self._h, 1 if enable else 0))
+
+    def kernel_time(self):
+        """(total kernel milliseconds, launches) since the last call; kernel only, HIP events on the launch stream."""
+        ms, n = ctypes.c_double(0.0), ctypes.c_int(0)
+        _capi.check(self._lib.adsp_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
 
     def synchronize(self, stream=None):
         _capi.check(self._lib.adsp_synchronize(self._h, _ptr(stream)))

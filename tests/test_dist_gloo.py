@@ -1,0 +1,92 @@
+"""Multi-process (gloo, world_size 2, CPU) tests of the N-GPU layer: contiguous channel shards, ONE
+broadcast of the filter spectrum from rank 0, zero steady-state communication.  The HIP engine is
+replaced by a numpy overlap-save stand-in that consumes the BROADCAST spectrum, so a wrong shard
+range or a spectrum that did not arrive shows up as a parity failure against the oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_parity
+
+
+def test_shard_range_partitions_exactly():
+    from pyaudiodsptools_amd.dist import shard_range
+    for total in (1, 2, 7, 8, 4096, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_range(65536, 8, 3) == (3 * 8192, 4 * 8192)  # config 4: 8192 channels per GPU
+
+
+class NumpyEngine:
+    """Stand-in for FirEngine on machines without a GPU: same geometry, spectrum supplied from outside."""
+
+    def __init__(self, fir, channels=1, device=0, ring_slots=0, fft_mult=0):
+        from pyaudiodsptools_amd.design import overlap_save_geometry
+        self.geometry = overlap_save_geometry(fir, fft_mult)
+        self.channels, self.n = channels, fir.chunk_size
+        self.hist = np.zeros((channels, self.geometry.history_chunks * self.n))
+        self.spec = None
+
+    def upload_spectrum(self, spectrum_f32):
+        self.spec = np.asarray(spectrum_f32, np.float32).view(np.complex64).astype(np.complex128)
+
+    def apply_host(self, x):  # x [C, N]
+        g, n = self.geometry, self.n
+        buf = np.concatenate([self.hist, x.astype(np.float64), np.zeros((self.channels, g.fft_size))], axis=1)
+        a = self.hist.shape[1] - g.lookback
+        y = np.fft.irfft(np.fft.rfft(buf[:, a:a + g.fft_size], axis=1) * self.spec, g.fft_size, axis=1)
+        self.hist = np.concatenate([self.hist, x], axis=1)[:, -self.hist.shape[1]:]
+        return y[:, g.out_offset:g.out_offset + n].astype(np.float32)
+
+
+def _worker(rank, world, port, total_channels, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from pyaudiodsptools_amd import design
+    from pyaudiodsptools_amd.dist import ShardedFirBank, init_process_group
+    init_process_group("gloo")
+    n, fs, steps = 512, 44100, 5
+    # only rank 0 holds the real design; other ranks start from a WRONG filter to prove the broadcast is used
+    cutoff = 800 if rank == 0 else 5000
+    fir = design.FirStream(design.lowcut_kernel(cutoff, fs, n), n)
+    bank = ShardedFirBank(fir, total_channels, device=0, engine_factory=NumpyEngine)
+    x = np.random.default_rng(99).uniform(-1, 1, (steps, total_channels, n)).astype(np.float32)
+    mine = x[:, bank.lo:bank.hi]
+    y = np.stack([bank.engine.apply_host(mine[k]) for k in range(steps)])
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), lo=bank.lo, hi=bank.hi, y=y, spec=bank.spectrum)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("total_channels", [6, 7])
+def test_two_rank_sharded_filter_matches_oracle(tmp_path, total_channels):
+    import torch.multiprocessing as mp
+    from oracle import fftfilter_oracle as orc
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), total_channels, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    assert int(parts[0]["lo"]) == 0 and int(parts[-1]["hi"]) == total_channels and int(parts[0]["hi"]) == int(parts[1]["lo"])
+    assert np.array_equal(parts[0]["spec"], parts[1]["spec"])  # bit-identical spectra on every rank
+    y = np.concatenate([p["y"] for p in parts], axis=1)
+    n, steps = 512, 5
+    x = np.random.default_rng(99).uniform(-1, 1, (steps, total_channels, n)).astype(np.float32)
+    for c in range(total_channels):
+        ref = orc.OracleLowCut(800, 44100, n)
+        want = np.concatenate([ref.apply(x[k, c]) for k in range(steps)])
+        assert_parity(y[:, c].reshape(-1), want, what=f"channel {c}")
