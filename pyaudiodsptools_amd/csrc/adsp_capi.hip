@@ -41,7 +41,7 @@ int fail(int code, const char* fmt, ...) {
 // plan registry
 // ------------------------------------------------------------------------------------------
 struct PlanInfo {
-    int M, FN, P, T, CPB, NP;  // FN = fft_size / chunk_size
+    int M, FN, P, T, CPB, NP, XL;  // FN = fft_size / chunk_size; XL = cross-lane pairing plan
     int rad[4];
     int tw_total;
     int lds_bytes;
@@ -63,7 +63,7 @@ hipError_t prepare_impl() {
 
 template <class PL, int CPB, int FN>
 constexpr PlanInfo make_plan() {
-    return PlanInfo{PL::M, FN, PL::P, PL::T, CPB, PL::NP, {PL::fwd(0), PL::fwd(1), PL::fwd(2), PL::fwd(3)},
+    return PlanInfo{PL::M, FN, PL::P, PL::T, CPB, PL::NP, PL::XL ? 1 : 0, {PL::fwd(0), PL::fwd(1), PL::fwd(2), PL::fwd(3)},
                     PL::tw_total, PL::M * CPB * (int)sizeof(float2), &launch_impl<PL, CPB, FN>, &prepare_impl<PL, CPB, FN>};
 }
 
@@ -94,6 +94,7 @@ const PlanInfo kVariants[] = {
     make_plan<Plan<4096, 16, 4, 16, 16, 2, 8>, 1, 2>(),  // 1
     make_plan<Plan<4096, 16, 4, 8, 8, 8, 8>, 1, 2>(),    // 2
     make_plan<Plan<4096, 16, 4, 4, 16, 8, 8>, 1, 2>(),   // 3
+    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 2>(),  // 4: cross-lane pairing
 };
 
 const PlanInfo* find_plan(int M, int FN) {
@@ -195,13 +196,22 @@ int set_device(const adsp_engine* e) {
 
 int upload_pairs(adsp_engine* e, const float* H, hipStream_t stream) {
     const PlanInfo& pl = *e->plan;
-    const int M = e->M, T = pl.T, R = pl.P / 2;
+    const int M = e->M, T = pl.T;
+    const int R = pl.XL ? pl.P : pl.P / 2;   // radix of the paired passes
+    const int D = M / R;                     // bin spacing between a butterfly's outputs
+    const int npairs = pl.XL ? R / 2 : R;    // pair ops per regular thread
+    auto first_bin = [&](int t) {            // the butterfly whose outputs thread t pairs (k = bin + D*r)
+        if (!pl.XL) return t;
+        const int lo = 32 * (t >> 6) + (t & 31);
+        return (t & 32) ? (t == 32 ? T / 2 : T - lo) : lo;
+    };
     // float4 layout [h][3][T]: (wc,g1) of pair 2h, (g2 of 2h, wc of 2h+1), (g1,g2) of 2h+1
-    std::vector<float4> tab((size_t)(R / 2) * 3 * T, make_float4(0.f, 0.f, 0.f, 0.f));
-    for (int h = 0; h < R / 2; ++h)
-        for (int tid = 1; tid < T; ++tid) {
-            const PairEntry a = pair_entry(H, M, tid + 2 * T * (2 * h));
-            const PairEntry b = pair_entry(H, M, tid + 2 * T * (2 * h + 1));
+    std::vector<float4> tab((size_t)(npairs / 2) * 3 * T, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int h = 0; h < npairs / 2; ++h)
+        for (int tid = 0; tid < T; ++tid) {
+            if (tid == 0 || (pl.XL && tid == 32)) continue;  // self-paired butterflies: tab0
+            const PairEntry a = pair_entry(H, M, first_bin(tid) + D * (2 * h));
+            const PairEntry b = pair_entry(H, M, first_bin(tid) + D * (2 * h + 1));
             tab[(size_t)(h * 3 + 0) * T + tid] = make_float4(a.wc.x, a.wc.y, a.g1.x, a.g1.y);
             tab[(size_t)(h * 3 + 1) * T + tid] = make_float4(a.g2.x, a.g2.y, b.wc.x, b.wc.y);
             tab[(size_t)(h * 3 + 2) * T + tid] = make_float4(b.g1.x, b.g1.y, b.g2.x, b.g2.y);
@@ -215,8 +225,8 @@ int upload_pairs(adsp_engine* e, const float* H, hipStream_t stream) {
     };
     put0(0, 0);
     put0(1, M / 2);
-    for (int r = 1; r < R / 2; ++r) put0(2 + (r - 1), 2 * T * r);
-    for (int r = 0; r < R / 2; ++r) put0(2 + (R / 2 - 1) + r, T + 2 * T * r);
+    for (int r = 1; r < R / 2; ++r) put0(2 + (r - 1), D * r);
+    for (int r = 0; r < R / 2; ++r) put0(2 + (R / 2 - 1) + r, D / 2 + D * r);
     // synchronous copies from pageable memory: safe to free the vectors on return
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipMemcpy(e->pair, tab.data(), tab.size() * sizeof(float4), hipMemcpyHostToDevice));
@@ -364,8 +374,8 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     if ((err = hipMalloc(&e->tw, tw_bytes)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
     if (!tw.empty() && (err = hipMemcpy(e->tw, tw.data(), tw.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess)
         return bail(fail(ADSP_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(err)));
-    const int R = pl->P / 2;
-    if ((err = hipMalloc(&e->pair, (size_t)(R / 2) * 3 * pl->T * sizeof(float4))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
+    const int R = pl->XL ? pl->P : pl->P / 2;
+    if ((err = hipMalloc(&e->pair, (size_t)R * 3 * pl->T * sizeof(float4))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
     if ((err = hipMalloc(&e->pair0, (size_t)(R + 1) * 3 * sizeof(float2))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
     if ((err = hipMalloc(&e->zeros, (size_t)N * sizeof(float))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
     if ((err = hipMemset(e->zeros, 0, (size_t)N * sizeof(float))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMemset: %s", hipGetErrorString(err)));

@@ -67,9 +67,12 @@ struct KernelArgs {
 // compile-time plan: M complex points, P points per thread, up to 4 forward radices.
 // Inverse radices are the forward ones reversed; the last forward radix must be P/2.
 // ------------------------------------------------------------------------------------------
-template <int M_, int P_, int NP_, int A0, int A1, int A2, int A3>
+// XL_ = cross-lane pairing: every pass has ONE butterfly per thread (last radix == P) and the real-FFT
+// partner of lane l lives in lane l ^ 32 of the same wave (needs T % 64 == 0).
+template <int M_, int P_, int NP_, int A0, int A1, int A2, int A3, bool XL_ = false>
 struct Plan {
     static constexpr int M = M_, P = P_, NP = NP_, T = M_ / P_;
+    static constexpr bool XL = XL_;
     static constexpr int fwd(int p) { return p == 0 ? A0 : p == 1 ? A1 : p == 2 ? A2 : A3; }
     static constexpr int inv(int p) { return fwd(NP_ - 1 - p); }
     static constexpr int rad(bool inverse, int p) { return inverse ? inv(p) : fwd(p); }
@@ -91,8 +94,9 @@ struct Plan {
         return n;
     }
     static constexpr int tw_total = tw_count(false) + tw_count(true);
-    static constexpr int RL = P_ / 2;  // radix of the paired passes
-    static_assert(fwd(NP_ - 1) == P_ / 2, "last forward radix must be P/2 (two butterflies per thread)");
+    static constexpr int RL = XL_ ? P_ : P_ / 2;  // radix of the paired passes
+    static_assert(fwd(NP_ - 1) == RL, "last forward radix must be P/2 (two butterflies per thread), or P for XL plans");
+    static_assert(!XL_ || (M_ / P_) % 64 == 0, "XL plans need whole waves");
     static_assert(stride(false, NP_) == M_, "radices must multiply to M");
 };
 
@@ -222,7 +226,7 @@ struct Pass {
     static constexpr bool PAIRED = INV ? (p == 0) : (p == PL::NP - 1);
     static constexpr bool LAST = (p == PL::NP - 1);
     static constexpr int TWOFF = PL::tw_offset(INV, p);
-    static_assert(!PAIRED || NB == 2, "paired pass needs exactly two butterflies per thread");
+    static_assert(!PAIRED || NB == (PL::XL ? 1 : 2), "paired pass: two butterflies per thread (one for XL plans)");
 
     static __device__ __forceinline__ int bfly(int i, int tid, int ja, int jb) {
         if constexpr (PAIRED) return i == 0 ? ja : jb;
@@ -302,15 +306,17 @@ struct Pass {
                 ai[m] = v.y;
             }
         } else {
-            constexpr int Rn = PL::RL;
+            constexpr int Rn = PL::RL, NBn = P / Rn;
 #pragma unroll
             for (int q = 0; q < Rn; ++q) {
                 const float2 va = lds[lds_phys<R, S == 1>(ja + q * (M / Rn))];
-                const float2 vb = lds[lds_phys<R, S == 1>(jb + q * (M / Rn))];
-                ar[2 * q] = va.x;
-                ai[2 * q] = va.y;
-                ar[2 * q + 1] = vb.x;
-                ai[2 * q + 1] = vb.y;
+                ar[NBn * q] = va.x;
+                ai[NBn * q] = va.y;
+                if constexpr (NBn == 2) {
+                    const float2 vb = lds[lds_phys<R, S == 1>(jb + q * (M / Rn))];
+                    ar[2 * q + 1] = vb.x;
+                    ai[2 * q + 1] = vb.y;
+                }
             }
         }
     }
@@ -406,46 +412,169 @@ __device__ __forceinline__ void spectrum_stage(float (&xr)[PL::P], float (&xi)[P
 }
 
 // ------------------------------------------------------------------------------------------
+// XL plans: the same stage when Z[k] (this lane, register r, k = jx + D r) and Z[M-k] (lane ^ 32, register
+// R-1-r) sit in different lanes.  Registers R/2..R-1 are exchanged between the two half-waves with
+// v_permlane32_swap (A.upper <-> B.lower; two swaps per register pair (i, i+1) leave partner's old register
+// i^1 in my register i), each lane then owns R/2 complete pairs, and the same swaps bring the results home.
+// Lanes 0 and 32 of wave 0 hold the two self-paired butterflies (j = 0 and j = D/2) and pair in-lane.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void half_swap(float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+
+template <int P>
+__device__ __forceinline__ void exchange_upper_half(float (&xr)[P], float (&xi)[P]) {
+#pragma unroll
+    for (int i = P / 2; i < P; i += 2) {
+        half_swap(xr[i], xr[i + 1]);
+        half_swap(xr[i + 1], xr[i]);
+        half_swap(xi[i], xi[i + 1]);
+        half_swap(xi[i + 1], xi[i]);
+    }
+}
+
+template <class PL>
+__device__ __forceinline__ void spectrum_stage_xl(float (&xr)[PL::P], float (&xi)[PL::P],
+                                                  const float4* __restrict__ pair, const float2* __restrict__ pair0,
+                                                  int t) {
+    constexpr int R = PL::P, T = PL::T;
+    if (t != 0 && t != 32) {
+        exchange_upper_half<R>(xr, xi);
+#pragma unroll
+        for (int h = 0; h < R / 4; ++h) {
+#if ADSP_ABLATE & 2
+            const float4 f0 = pair[(t & 1)], f1 = pair[T + (t & 1)], f2 = pair[2 * T + (t & 1)];
+#else
+            const float4 f0 = pair[(h * 3 + 0) * T + t];
+            const float4 f1 = pair[(h * 3 + 1) * T + t];
+            const float4 f2 = pair[(h * 3 + 2) * T + t];
+#endif
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int r0 = 2 * h, r1 = 2 * h + 1;
+            pair_op(xr[r0], xi[r0], xr[(R - 1 - r0) ^ 1], xi[(R - 1 - r0) ^ 1], make_float2(f0.x, f0.y),
+                    make_float2(f0.z, f0.w), make_float2(f1.x, f1.y));
+            pair_op(xr[r1], xi[r1], xr[(R - 1 - r1) ^ 1], xi[(R - 1 - r1) ^ 1], make_float2(f1.z, f1.w),
+                    make_float2(f2.x, f2.y), make_float2(f2.z, f2.w));
+        }
+        exchange_upper_half<R>(xr, xi);
+    } else if (t == 0) {
+        // j = 0: bins D*r.  entry 0: k = 0, entry 1: k = M/2 (r = R/2), entries 2..: (r, R-r), r = 1..R/2-1
+        {
+            float tr = xr[0], ti = xi[0];
+            pair_op(xr[0], xi[0], tr, ti, pair0[0], pair0[1], pair0[2]);
+        }
+        {
+            float tr = xr[R / 2], ti = xi[R / 2];
+            pair_op(xr[R / 2], xi[R / 2], tr, ti, pair0[3], pair0[4], pair0[5]);
+        }
+#pragma unroll
+        for (int r = 1; r < R / 2; ++r) {
+            const int e = 2 + (r - 1);
+            pair_op(xr[r], xi[r], xr[R - r], xi[R - r], pair0[e * 3], pair0[e * 3 + 1], pair0[e * 3 + 2]);
+        }
+    } else {
+        // j = D/2: bins D/2 + D*r pair (r, R-1-r)
+#pragma unroll
+        for (int r = 0; r < R / 2; ++r) {
+            const int e = 2 + (R / 2 - 1) + r;
+            pair_op(xr[r], xi[r], xr[R - 1 - r], xi[R - 1 - r], pair0[e * 3], pair0[e * 3 + 1], pair0[e * 3 + 2]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // window load / kept-sample store with compile-time chunk geometry.
 // FN = F/N (2 or 4).  MPC = P/FN registers per chunk; windows and kept ranges start on quarter-chunk
 // boundaries, so (phase RQ in 0..3, register m) -> (chunk index, offset) is known at compile time.
 // ------------------------------------------------------------------------------------------
+// neighbour-lane exchange (lane ^ 1) as a DPP quad permute [1,0,3,2]
+__device__ __forceinline__ float lane_xor1(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1, 0xF, 0xF, true));
+}
+
+// 16-byte global accesses.  A thread owns elements tid + T*m (8 bytes each).  For a register pair (2u, 2u+1) the
+// even lane of a lane pair fetches 16 bytes at element tid of register 2u (its own value + its neighbour's), the
+// odd lane 16 bytes at element tid-1 of register 2u+1 (its neighbour's + its own); one DPP swap per float puts every
+// value home.  Same bytes, half the vector-memory instructions (a dwordx2 costs the TA what a dwordx4 does).
+// `cb`/`ob` pointers passed in already carry the per-lane adjustment (+2T-2 floats on odd lanes).
 template <class PL, int FN, int RQ>
-__device__ __forceinline__ void load_window(const float* const (&cb)[FN + 1], float (&xr)[PL::P], float (&xi)[PL::P]) {
+__device__ __forceinline__ void load_window(const float* const (&cb)[FN + 1], float (&xr)[PL::P], float (&xi)[PL::P],
+                                            bool odd) {
     constexpr int P = PL::P, T = PL::T, MPC = P / FN, Q = MPC / 4;
     static_assert(MPC % 4 == 0, "need at least 4 registers per chunk");
+    if constexpr (Q % 2 == 0) {
 #pragma unroll
-    for (int m = 0; m < P; ++m) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int gi = RQ * Q + m;
-        const int i = gi / MPC;
-        const int off = (gi % MPC) * 2 * T;
+        for (int u = 0; u < P / 2; ++u) {
+            const int gi = RQ * Q + 2 * u;  // registers 2u and 2u+1 are always in the same chunk
+            const int i = gi / MPC;
+            const int off = (gi % MPC) * 2 * T;
 #if ADSP_ABLATE & 8
-        const float2 v = make_float2(static_cast<float>(off + i) * 1e-4f, reinterpret_cast<size_t>(cb[i]) * 1e-20f);
+            const float4 v = make_float4(static_cast<float>(off + i) * 1e-4f, reinterpret_cast<size_t>(cb[i]) * 1e-20f, 1.f, 2.f);
 #else
-        const float2 v = *reinterpret_cast<const float2*>(cb[i] + off);
+            const float4 v = *reinterpret_cast<const float4*>(cb[i] + off);
 #endif
-        xr[m] = v.x;
-        xi[m] = v.y;
+            const float sx = lane_xor1(odd ? v.x : v.z), sy = lane_xor1(odd ? v.y : v.w);  // what the neighbour needs
+            xr[2 * u] = odd ? sx : v.x;
+            xi[2 * u] = odd ? sy : v.y;
+            xr[2 * u + 1] = odd ? v.z : sx;
+            xi[2 * u + 1] = odd ? v.w : sy;
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < P; ++m) {
+            const int gi = RQ * Q + m;
+            const int i = gi / MPC;
+            const int off = (gi % MPC) * 2 * T;
+#if ADSP_ABLATE & 8
+            const float2 v = make_float2(static_cast<float>(off + i) * 1e-4f, reinterpret_cast<size_t>(cb[i]) * 1e-20f);
+#else
+            const float2 v = *reinterpret_cast<const float2*>(cb[i] + off);
+#endif
+            xr[m] = v.x;
+            xi[m] = v.y;
+        }
     }
 }
 
 template <class PL, int FN, int RQ>
 __device__ __forceinline__ void store_kept(float* const (&ob)[FN + 1], const float (&xr)[PL::P],
-                                           const float (&xi)[PL::P], int m_lo, int m_hi) {
+                                           const float (&xi)[PL::P], int m_lo, int m_hi, bool odd) {
     constexpr int P = PL::P, T = PL::T, MPC = P / FN, Q = MPC / 4;
+    if constexpr (Q % 2 == 0) {
 #pragma unroll
-    for (int m = 0; m < P; ++m) {
-        if (m >= m_lo && m < m_hi) {  // wave-uniform
-            const int gi = RQ * Q + m;
-            const int i = gi / MPC;
-            const int off = (gi % MPC) * 2 * T;
+        for (int u = 0; u < P / 2; ++u) {
+            if (2 * u >= m_lo && 2 * u < m_hi) {  // wave-uniform; kept ranges start/end on even registers
+                const int gi = RQ * Q + 2 * u;
+                const int i = gi / MPC;
+                const int off = (gi % MPC) * 2 * T;
+                // even lane stores (own, neighbour's) of register 2u; odd lane (neighbour's, own) of register 2u+1
+                const float sx = lane_xor1(odd ? xr[2 * u] : xr[2 * u + 1]);
+                const float sy = lane_xor1(odd ? xi[2 * u] : xi[2 * u + 1]);
+                const float4 v = odd ? make_float4(sx, sy, xr[2 * u + 1], xi[2 * u + 1])
+                                     : make_float4(xr[2 * u], xi[2 * u], sx, sy);
 #if ADSP_ABLATE & 16
-            if (xr[m] == 123.456f) *reinterpret_cast<float2*>(ob[i] + off) = make_float2(xr[m], xi[m]);
+                if (xr[2 * u] == 123.456f) *reinterpret_cast<float4*>(ob[i] + off) = v;
 #else
-            *reinterpret_cast<float2*>(ob[i] + off) = make_float2(xr[m], xi[m]);
+                *reinterpret_cast<float4*>(ob[i] + off) = v;
 #endif
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < P; ++m) {
+            if (m >= m_lo && m < m_hi) {  // wave-uniform
+                const int gi = RQ * Q + m;
+                const int i = gi / MPC;
+                const int off = (gi % MPC) * 2 * T;
+#if ADSP_ABLATE & 16
+                if (xr[m] == 123.456f) *reinterpret_cast<float2*>(ob[i] + off) = make_float2(xr[m], xi[m]);
+#else
+                *reinterpret_cast<float2*>(ob[i] + off) = make_float2(xr[m], xi[m]);
+#endif
+            }
         }
     }
 }
@@ -481,7 +610,10 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(con
     const int o = blk * a.V;        // first output-time of this block (multiple of N/4)
     const int t0 = o - a.lookback;  // first input-time of the window (multiple of N/4)
     const size_t plane = static_cast<size_t>(a.C) << LOGN;  // one [C][N] chunk batch
-    const size_t chan_off = (static_cast<size_t>(c) << LOGN) + 2 * tid;
+    // 16-byte I/O: odd lanes address the neighbour pair of the NEXT register (element tid-1, +2T floats further on)
+    constexpr bool WIDE = ((P / FN) / 4) % 2 == 0;
+    const bool odd = WIDE && (tid & 1);
+    const size_t chan_off = (static_cast<size_t>(c) << LOGN) + 2 * tid + (odd ? 2 * T - 2 : 0);
 
     // The window touches at most FN + 1 chunks.  Resolve each to a pointer once: ring history, new
     // input, or the zero page for chunks that do not exist yet / channels past the end.
@@ -490,7 +622,7 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(con
 #pragma unroll
     for (int i = 0; i < FN + 1; ++i) {
         const int q = q0 + i;
-        const float* base = a.zeros + 2 * tid;
+        const float* base = a.zeros + 2 * tid + (odd ? 2 * T - 2 : 0);
         if (chan_ok && q < a.n_steps) {
             if (q < 0) {
                 int slot = a.ring_pos + 1 + q;
@@ -506,17 +638,28 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(con
 
     float xr[P], xi[P];
     switch ((t0 & (N - 1)) >> (LOGN - 2)) {  // window phase within its first chunk, in quarter chunks
-        case 0: load_window<PL, FN, 0>(cb, xr, xi); break;
-        case 1: load_window<PL, FN, 1>(cb, xr, xi); break;
-        case 2: load_window<PL, FN, 2>(cb, xr, xi); break;
-        default: load_window<PL, FN, 3>(cb, xr, xi); break;
+        case 0: load_window<PL, FN, 0>(cb, xr, xi, odd); break;
+        case 1: load_window<PL, FN, 1>(cb, xr, xi, odd); break;
+        case 2: load_window<PL, FN, 2>(cb, xr, xi, odd); break;
+        default: load_window<PL, FN, 3>(cb, xr, xi, odd); break;
     }
 
-    const int ja = tid;
-    const int jb = (tid == 0) ? T : 2 * T - tid;
+    int ja, jb;
+    if constexpr (PL::XL) {
+        // lanes 0-31 of wave w: butterflies 32w + l; lanes 32-63: their partners T - (32w + l)
+        const int lo = 32 * (tid >> 6) + (tid & 31);
+        ja = (tid & 32) ? (tid == 32 ? T / 2 : T - lo) : lo;
+        jb = 0;
+    } else {
+        ja = tid;
+        jb = (tid == 0) ? T : 2 * T - tid;
+    }
 
     run_passes<PL, false, 0>(xr, xi, lds, a.tw, tid, ja, jb);
-    spectrum_stage<PL>(xr, xi, a.pair, a.pair0, tid);
+    if constexpr (PL::XL)
+        spectrum_stage_xl<PL>(xr, xi, a.pair, a.pair0, tid);
+    else
+        spectrum_stage<PL>(xr, xi, a.pair, a.pair0, tid);
     run_passes<PL, true, 0>(xi, xr, lds, a.tw, tid, ja, jb);  // inverse = forward on swapped parts
 
     // kept samples: circular indices [j0, j0 + keep) -> registers m_lo <= m < m_hi; register m holds
@@ -535,10 +678,10 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(con
     }
     if (chan_ok) {
         switch ((s & (N - 1)) >> (LOGN - 2)) {
-            case 0: store_kept<PL, FN, 0>(ob, xr, xi, m_lo, m_hi); break;
-            case 1: store_kept<PL, FN, 1>(ob, xr, xi, m_lo, m_hi); break;
-            case 2: store_kept<PL, FN, 2>(ob, xr, xi, m_lo, m_hi); break;
-            default: store_kept<PL, FN, 3>(ob, xr, xi, m_lo, m_hi); break;
+            case 0: store_kept<PL, FN, 0>(ob, xr, xi, m_lo, m_hi, odd); break;
+            case 1: store_kept<PL, FN, 1>(ob, xr, xi, m_lo, m_hi, odd); break;
+            case 2: store_kept<PL, FN, 2>(ob, xr, xi, m_lo, m_hi, odd); break;
+            default: store_kept<PL, FN, 3>(ob, xr, xi, m_lo, m_hi, odd); break;
         }
     }
 }
