@@ -72,7 +72,8 @@ typedef struct adsp_config {
     int history_chunks;  /* past chunks the window can reach (1..ADSP_MAX_HISTORY) */
     int lookback;        /* see above; 0 < lookback <= history_chunks*N, multiple of 4N/.. (checked) */
     int out_offset;      /* see above */
-    int ring_slots;      /* input ring length for the zero-copy streaming path; 0 = history_chunks+1 */
+    int ring_slots;      /* input ring length (>= history_chunks+1); 0 = 2*history_chunks, which lets the ring
+                            update of multi-step launches run on a side stream beside the kernel */
 } adsp_config;
 
 /* ABI version (ADSP_ABI_VERSION of the built library). */

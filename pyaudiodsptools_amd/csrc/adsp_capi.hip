@@ -81,8 +81,8 @@ const PlanInfo kPlans[] = {
     make_plan<Plan<1024, 16, 3, 16, 8, 8, 1>, 1, 4>(),
     make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 2>(),
     make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 4>(),
-    make_plan<Plan<4096, 32, 3, 16, 16, 16, 1>, 1, 2>(),
-    make_plan<Plan<4096, 32, 3, 16, 16, 16, 1>, 1, 4>(),
+    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 2>(),  // cross-lane pairing: 4 waves, 96 VGPRs
+    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 4>(),
     make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1, 2>(),
     make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1, 4>(),
     make_plan<Plan<16384, 32, 4, 32, 2, 16, 16>, 1, 4>(),
@@ -94,7 +94,7 @@ const PlanInfo kVariants[] = {
     make_plan<Plan<4096, 16, 4, 16, 16, 2, 8>, 1, 2>(),  // 1
     make_plan<Plan<4096, 16, 4, 8, 8, 8, 8>, 1, 2>(),    // 2
     make_plan<Plan<4096, 16, 4, 4, 16, 8, 8>, 1, 2>(),   // 3
-    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 2>(),  // 4: cross-lane pairing
+    make_plan<Plan<4096, 32, 3, 16, 16, 16, 1>, 1, 2>(),   // 4: in-register pairing, 2 waves, 193 VGPRs
 };
 
 const PlanInfo* find_plan(int M, int FN) {
@@ -182,6 +182,9 @@ struct adsp_engine {
     float* stage_out;
     size_t stage_elems;
     bool timing;
+    hipStream_t copy_stream;  // ring update of multi-step launches runs beside the kernel
+    hipEvent_t ev_in_ready, ev_copy_done;
+    bool copy_pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;   // recorded, not yet read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_ev;  // recycled event pairs
     size_t plane() const { return (size_t)cfg.n_channels * (size_t)cfg.chunk_size; }
@@ -331,7 +334,8 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     // kept sample i sits at input-time o - lookback + out_offset + i; it may not lie beyond the newest chunk
     if (cfg->out_offset > cfg->lookback)
         return fail(ADSP_ERR_ARG, "out_offset %d > lookback %d: kept samples would need future input", cfg->out_offset, cfg->lookback);
-    int slots = cfg->ring_slots == 0 ? cfg->history_chunks + 1 : cfg->ring_slots;
+    int slots = cfg->ring_slots == 0 ? 2 * cfg->history_chunks : cfg->ring_slots;
+    if (slots < 2) slots = 2;
     if (slots < cfg->history_chunks + 1) return fail(ADSP_ERR_ARG, "ring_slots must be >= history_chunks + 1");
 
     int ndev = 0;
@@ -356,6 +360,9 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     e->stage_in = e->stage_out = nullptr;
     e->stage_elems = 0;
     e->timing = false;
+    e->copy_stream = nullptr;
+    e->ev_in_ready = e->ev_copy_done = nullptr;
+    e->copy_pending = false;
 
     auto bail = [&](int code) {
         adsp_destroy(e);
@@ -377,6 +384,9 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     const int R = pl->XL ? pl->P : pl->P / 2;
     if ((err = hipMalloc(&e->pair, (size_t)R * 3 * pl->T * sizeof(float4))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
     if ((err = hipMalloc(&e->pair0, (size_t)(R + 1) * 3 * sizeof(float2))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
+    if ((err = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(err)));
+    if ((err = hipEventCreateWithFlags(&e->ev_in_ready, hipEventDisableTiming)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(err)));
+    if ((err = hipEventCreateWithFlags(&e->ev_copy_done, hipEventDisableTiming)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(err)));
     if ((err = hipMalloc(&e->zeros, (size_t)N * sizeof(float))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
     if ((err = hipMemset(e->zeros, 0, (size_t)N * sizeof(float))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMemset: %s", hipGetErrorString(err)));
     *out_engine = e;
@@ -392,6 +402,9 @@ int adsp_destroy(adsp_engine* e) {
     if (e->pair) (void)hipFree(e->pair);
     if (e->pair0) (void)hipFree(e->pair0);
     if (e->zeros) (void)hipFree(e->zeros);
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+    if (e->ev_in_ready) (void)hipEventDestroy(e->ev_in_ready);
+    if (e->ev_copy_done) (void)hipEventDestroy(e->ev_copy_done);
     if (e->stage_in) (void)hipFree(e->stage_in);
     if (e->stage_out) (void)hipFree(e->stage_out);
     for (auto& v : {&e->timed, &e->free_ev})
@@ -441,6 +454,7 @@ int adsp_reset(adsp_engine* e) {
     int rc = set_device(e);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
+    e->copy_pending = false;
     HIP_TRY(hipMemset(e->ring, 0, (size_t)e->cfg.ring_slots * e->plane() * sizeof(float)));
     e->ring_pos = e->cfg.ring_slots - 1;
     return ADSP_OK;
@@ -453,15 +467,29 @@ int adsp_apply_device(adsp_engine* e, const float* d_in, float* d_out, int n_ste
     int rc = set_device(e);
     if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_v;
-    if ((rc = launch(e, d_in, d_out, n_steps, stream))) return rc;
-    // carry the newest chunks into the ring (stream-ordered after the kernel)
     const int S = e->cfg.ring_slots;
     const int cnt = n_steps < e->cfg.history_chunks ? n_steps : e->cfg.history_chunks;
     const size_t plane = e->plane();
+    // The newest `cnt` chunks must end up in the ring.  They go to slots the kernel does not read when the ring has
+    // >= 2*history slots, so the copy can run on a side stream BESIDE the kernel: it waits for the caller's input
+    // (event on `stream` before the launch) and the next launch on any stream waits for it (event after the copy).
+    const bool side = (S >= 2 * e->cfg.history_chunks) && n_steps > 1;
+    if (e->copy_pending) {  // a previous side copy must have landed before this kernel reads the ring
+        HIP_TRY(hipStreamWaitEvent(stream, e->ev_copy_done, 0));
+        e->copy_pending = false;
+    }
+    if (side) HIP_TRY(hipEventRecord(e->ev_in_ready, stream));
+    if ((rc = launch(e, d_in, d_out, n_steps, stream))) return rc;
+    hipStream_t cs = side ? e->copy_stream : stream;
+    if (side) HIP_TRY(hipStreamWaitEvent(cs, e->ev_in_ready, 0));
     for (int i = 0; i < cnt; ++i) {
         const int slot = (e->ring_pos + 1 + i) % S;
         const float* src = d_in + (size_t)(n_steps - cnt + i) * plane;
-        HIP_TRY(hipMemcpyAsync(e->ring + (size_t)slot * plane, src, plane * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(e->ring + (size_t)slot * plane, src, plane * sizeof(float), hipMemcpyDeviceToDevice, cs));
+    }
+    if (side) {
+        HIP_TRY(hipEventRecord(e->ev_copy_done, cs));
+        e->copy_pending = true;
     }
     e->ring_pos = (e->ring_pos + cnt) % S;
     return ADSP_OK;
@@ -479,6 +507,10 @@ int adsp_apply_ring(adsp_engine* e, float* d_out, void* stream_v) {
     if (!e->have_spectrum) return fail(ADSP_ERR_STATE, "adsp_set_spectrum has not been called");
     int rc = set_device(e);
     if (rc) return rc;
+    if (e->copy_pending) {
+        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream_v, e->ev_copy_done, 0));
+        e->copy_pending = false;
+    }
     const int slot = (e->ring_pos + 1) % e->cfg.ring_slots;
     if ((rc = launch(e, e->ring + (size_t)slot * e->plane(), d_out, 1, (hipStream_t)stream_v))) return rc;
     e->ring_pos = slot;
@@ -512,6 +544,7 @@ int adsp_get_state(adsp_engine* e, float* host_history) {
     int rc = set_device(e);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
+    e->copy_pending = false;
     const int S = e->cfg.ring_slots, nh = e->cfg.history_chunks;
     const size_t plane = e->plane();
     for (int h = 0; h < nh; ++h) {  // h = 0 oldest (time step -nh)

@@ -38,7 +38,7 @@ class FirEngine:
         cfg = _capi.AdspConfig(self.device, self.chunk_size, self.channels, geo.fft_size, geo.history_chunks,
                                geo.lookback, geo.out_offset, int(ring_slots))
         _capi.check(self._lib.adsp_create(ctypes.byref(cfg), ctypes.byref(self._h)))
-        self.ring_slots = int(ring_slots) if ring_slots else geo.history_chunks + 1
+        self.ring_slots = int(ring_slots) if ring_slots else max(2 * geo.history_chunks, geo.history_chunks + 1)
         self.plan = _capi.plan_describe(self.chunk_size, geo.fft_size)
         self.set_fir(fir)
         self.block_outputs = self.chunk_size
