@@ -136,7 +136,15 @@ void build_twiddles(const PlanInfo& pl, std::vector<float4>& tw) {
         int S = 1;
         for (int p = 0; p < pl.NP; ++p) {
             const int R = dir == 0 ? pl.rad[p] : pl.rad[pl.NP - 1 - p];
-            if (p > 0) {
+            if (p > 0 && R == 16) {
+                // two-level: (w^1,w^2), (w^3,w^4), (w^8,w^12) per jlo; the kernel forms w^(4a+b) = w^(4a) w^b
+                const int qs[3][2] = {{1, 2}, {3, 4}, {8, 12}};
+                for (int h = 0; h < 3; ++h)
+                    for (int jlo = 0; jlo < S; ++jlo) {
+                        const float2 a = tw1(qs[h][0], jlo, R, S), b = tw1(qs[h][1], jlo, R, S);
+                        tw.push_back(make_float4(a.x, a.y, b.x, b.y));
+                    }
+            } else if (p > 0) {
                 for (int h = 0; h < R / 2; ++h)
                     for (int jlo = 0; jlo < S; ++jlo) {
                         const float2 a = tw1(2 * h + 1, jlo, R, S);

@@ -81,16 +81,19 @@ struct Plan {
         for (int i = 0; i < p; ++i) s *= rad(inverse, i);
         return s;
     }
-    // twiddles are stored as float4 = (w_{2p+1}, w_{2p+2}), p < R/2, per j_lo: R/2 * S float4 per pass
-    // (one 16-byte load costs the TA exactly what an 8-byte one does: ~16 cycles per wave instruction)
+    // Twiddles are stored as float4 (one 16-byte load costs the TA exactly what an 8-byte one does).
+    //  radix 16: TWO-LEVEL, 3 float4 per j_lo = (w^1,w^2), (w^3,w^4), (w^8,w^12); the other nine powers
+    //            w^(4a+b) = w^(4a) * w^b are formed in registers (36 flops instead of 72 bytes of table per butterfly)
+    //  other radices: (w_{2h+1}, w_{2h+2}), h < R/2.
+    static constexpr int tw_rows(int radix) { return radix == 16 ? 3 : radix / 2; }
     static constexpr int tw_count(bool inverse) {
         int n = 0;
-        for (int p = 1; p < NP_; ++p) n += (rad(inverse, p) / 2) * stride(inverse, p);
+        for (int p = 1; p < NP_; ++p) n += tw_rows(rad(inverse, p)) * stride(inverse, p);
         return n;
     }
     static constexpr int tw_offset(bool inverse, int p) {
         int n = inverse ? tw_count(false) : 0;
-        for (int i = 1; i < p; ++i) n += (rad(inverse, i) / 2) * stride(inverse, i);
+        for (int i = 1; i < p; ++i) n += tw_rows(rad(inverse, i)) * stride(inverse, i);
         return n;
     }
     static constexpr int tw_total = tw_count(false) + tw_count(true);
@@ -243,7 +246,33 @@ struct Pass {
                 ur[q] = ar[i + q * NB];
                 ui[q] = ai[i + q * NB];
             }
-            if constexpr (S > 1) {
+            if constexpr (S > 1 && R == 16) {
+                // two-level twiddles: w^(4a+b) = w^(4a) * w^b
+                const int jlo = bfly(i, tid, ja, jb) & (S - 1);
+#if ADSP_ABLATE & 1
+                const float4 t0 = tw[TWOFF + (jlo & 1)], t1 = tw[TWOFF + 2 + (jlo & 1)], t2 = tw[TWOFF + 4 + (jlo & 1)];
+#else
+                const float4 t0 = tw[TWOFF + jlo], t1 = tw[TWOFF + S + jlo], t2 = tw[TWOFF + 2 * S + jlo];
+#endif
+                float wr[16], wi[16];
+                wr[1] = t0.x; wi[1] = t0.y; wr[2] = t0.z; wi[2] = t0.w;
+                wr[3] = t1.x; wi[3] = t1.y; wr[4] = t1.z; wi[4] = t1.w;
+                wr[8] = t2.x; wi[8] = t2.y; wr[12] = t2.z; wi[12] = t2.w;
+#pragma unroll
+                for (int a4 = 4; a4 < 16; a4 += 4) {
+#pragma unroll
+                    for (int b = 1; b < 4; ++b) {
+                        wr[a4 + b] = wr[a4] * wr[b] - wi[a4] * wi[b];
+                        wi[a4 + b] = wr[a4] * wi[b] + wi[a4] * wr[b];
+                    }
+                }
+#pragma unroll
+                for (int q = 1; q < 16; ++q) {
+                    const float xr = ur[q], xi = ui[q];
+                    ur[q] = xr * wr[q] - xi * wi[q];
+                    ui[q] = xr * wi[q] + xi * wr[q];
+                }
+            } else if constexpr (S > 1) {
                 const int jlo = bfly(i, tid, ja, jb) & (S - 1);
 #pragma unroll
                 for (int h = 0; h < R / 2; ++h) {
