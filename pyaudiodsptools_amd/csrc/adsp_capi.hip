@@ -162,13 +162,19 @@ struct PairEntry {
 };
 
 PairEntry pair_entry(const float* H, int M, int k) {
-    // wc = -i * exp(-i*pi*k/M);  g1 = H[k]/(4M);  g2 = conj(H[M-k])/(4M)
+    // the three entries (c1, c2, c4) of the 2x2 matrix of fftconv_kernel.hpp::pair_op, stored as (wc, g1, g2):
+    //   wc' = -i exp(-i pi k/M), g1 = H[k]/4M, g2 = conj(H[M-k])/4M, s = g1+g2, d = g1-g2
+    //   c1 = 2s + 2d Re(wc'), c2 = -2i d Im(wc'), c4 = 2s - 2d Re(wc')
     const double ang = M_PI * (double)k / (double)M;
     const double sc = 1.0 / (4.0 * (double)M);
+    const double wr = -std::sin(ang), wi = -std::cos(ang);
+    const double g1r = H[2 * k] * sc, g1i = H[2 * k + 1] * sc;
+    const double g2r = H[2 * (M - k)] * sc, g2i = -H[2 * (M - k) + 1] * sc;
+    const double sr = g1r + g2r, si = g1i + g2i, dr = g1r - g2r, di = g1i - g2i;
     PairEntry e;
-    e.wc = make_float2((float)(-std::sin(ang)), (float)(-std::cos(ang)));
-    e.g1 = make_float2((float)(H[2 * k] * sc), (float)(H[2 * k + 1] * sc));
-    e.g2 = make_float2((float)(H[2 * (M - k)] * sc), (float)(-H[2 * (M - k) + 1] * sc));
+    e.wc = make_float2((float)(2 * sr + 2 * dr * wr), (float)(2 * si + 2 * di * wr));  // c1
+    e.g1 = make_float2((float)(2 * di * wi), (float)(-2 * dr * wi));                    // c2 = -2i d Im(wc')
+    e.g2 = make_float2((float)(2 * sr - 2 * dr * wr), (float)(2 * si - 2 * di * wr));  // c4
     return e;
 }
 

@@ -33,9 +33,14 @@
 
 // ADSP_ABLATE: tuning-only bitmask that removes one ingredient of the kernel to see what it costs
 // (results are then wrong).  1: pass twiddles not loaded  2: pair tables not loaded  4: no LDS exchange
-// 8: no global input loads  16: no output stores  32: butterflies replaced by copies.  Never set in product builds.
+// 8: no global input loads  16: no output stores  32: butterflies replaced by copies  64: I/O aliased onto 8 channels.  Never set in product builds.
 #ifndef ADSP_ABLATE
 #define ADSP_ABLATE 0
+#endif
+
+// ADSP_NT: bit 0 = non-temporal output stores, bit 1 = non-temporal input loads (tuning A/B)
+#ifndef ADSP_NT
+#define ADSP_NT 1
 #endif
 
 #ifndef ADSP_MIN_WAVES
@@ -369,25 +374,26 @@ __device__ __forceinline__ void run_passes(float (&ar)[PL::P], float (&ai)[PL::P
 
 // ------------------------------------------------------------------------------------------
 // real-FFT split  +  spectrum multiply  +  re-pack for the inverse, on one (k, M-k) pair.
-//   wc = -i*W_2M^k,  g1 = H[k]/(4M),  g2 = conj(H[M-k])/(4M)
 //   in : za = Z[k], zb = Z[M-k]        out: za = Zy[k]/M, zb = Zy[M-k]/M
+// With U = Za + conj(Zb), D = Za - conj(Zb), wc = -i W_2M^k, g1 = H[k]/4M, g2 = conj(H[M-k])/4M the textbook chain
+//   X[k] ~ U + wc D,  conj(X[M-k]) ~ U - wc D,  P = g1 X1,  Q = g2 X2,  E = P + Q,  O = conj(wc)(P - Q),
+//   Zy[k] = E + O,  Zy[M-k] = conj(E - O)
+// is linear in (Za, conj Zb) and, because |wc| = 1, collapses to a 2x2 complex matrix with THREE distinct entries
+// (s = g1 + g2, d = g1 - g2):   c1 = 2s + 2d Re(wc),  c2 = -2i d Im(wc),  c4 = 2s - 2d Re(wc)
+//   Zy[k]   = c1 Za + c2 conj(Zb)
+//   Zy[M-k] = conj(c4 conj(Zb) - c2 Za)
+// 16 multiply-adds per pair (instead of 32 flops), 24 bytes of table per pair; the host builds c1, c2, c4 in float64.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void pair_op(float& zar, float& zai, float& zbr, float& zbi, const float2 wc,
-                                        const float2 g1, const float2 g2) {
-    const float ur = zar + zbr, ui = zai - zbi;  // U = Za + conj(Zb)
-    const float dr = zar - zbr, di = zai + zbi;  // D = Za - conj(Zb)
-    const float br = wc.x * dr - wc.y * di, bi = wc.x * di + wc.y * dr;
-    const float x1r = ur + br, x1i = ui + bi;  // 2 X[k]
-    const float x2r = ur - br, x2i = ui - bi;  // 2 conj(X[M-k])
-    const float pr = g1.x * x1r - g1.y * x1i, pi = g1.x * x1i + g1.y * x1r;
-    const float qr = g2.x * x2r - g2.y * x2i, qi = g2.x * x2i + g2.y * x2r;
-    const float er = pr + qr, ei = pi + qi;
-    const float odr = pr - qr, odi = pi - qi;
-    const float opr = wc.x * odr + wc.y * odi, opi = wc.x * odi - wc.y * odr;  // conj(wc) * Od
-    zar = er + opr;
-    zai = ei + opi;
-    zbr = er - opr;
-    zbi = opi - ei;
+__device__ __forceinline__ void pair_op(float& zar, float& zai, float& zbr, float& zbi, const float2 c1,
+                                        const float2 c2, const float2 c4) {
+    const float o1r = c1.x * zar - c1.y * zai + c2.x * zbr + c2.y * zbi;
+    const float o1i = c1.x * zai + c1.y * zar + c2.y * zbr - c2.x * zbi;
+    const float tr = c4.x * zbr + c4.y * zbi - c2.x * zar + c2.y * zai;
+    const float ti = c4.y * zbr - c4.x * zbi - c2.x * zai - c2.y * zar;
+    zar = o1r;
+    zai = o1i;
+    zbr = tr;
+    zbi = -ti;
 }
 
 template <class PL>
@@ -489,7 +495,9 @@ __device__ __forceinline__ void spectrum_stage_xl(float (&xr)[PL::P], float (&xi
                     make_float2(f2.x, f2.y), make_float2(f2.z, f2.w));
         }
         exchange_upper_half<R>(xr, xi);
-    } else if (t == 0) {
+    }
+#if !(ADSP_ABLATE & 128)
+    else if (t == 0) {
         // j = 0: bins D*r.  entry 0: k = 0, entry 1: k = M/2 (r = R/2), entries 2..: (r, R-r), r = 1..R/2-1
         {
             float tr = xr[0], ti = xi[0];
@@ -512,6 +520,7 @@ __device__ __forceinline__ void spectrum_stage_xl(float (&xr)[PL::P], float (&xi
             pair_op(xr[r], xi[r], xr[R - 1 - r], xi[R - 1 - r], pair0[e * 3], pair0[e * 3 + 1], pair0[e * 3 + 2]);
         }
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -543,7 +552,13 @@ __device__ __forceinline__ void load_window(const float* const (&cb)[FN + 1], fl
 #if ADSP_ABLATE & 8
             const float4 v = make_float4(static_cast<float>(off + i) * 1e-4f, reinterpret_cast<size_t>(cb[i]) * 1e-20f, 1.f, 2.f);
 #else
+#if ADSP_NT & 2
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f nv = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(cb[i] + off));
+            const float4 v = make_float4(nv.x, nv.y, nv.z, nv.w);
+#else
             const float4 v = *reinterpret_cast<const float4*>(cb[i] + off);
+#endif
 #endif
             const float sx = lane_xor1(odd ? v.x : v.z), sy = lane_xor1(odd ? v.y : v.w);  // what the neighbour needs
             xr[2 * u] = odd ? sx : v.x;
@@ -586,6 +601,10 @@ __device__ __forceinline__ void store_kept(float* const (&ob)[FN + 1], const flo
                                      : make_float4(xr[2 * u], xi[2 * u], sx, sy);
 #if ADSP_ABLATE & 16
                 if (xr[2 * u] == 123.456f) *reinterpret_cast<float4*>(ob[i] + off) = v;
+#elif ADSP_NT & 1
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                v4f nv = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(nv, reinterpret_cast<v4f*>(ob[i] + off));
 #else
                 *reinterpret_cast<float4*>(ob[i] + off) = v;
 #endif
@@ -642,7 +661,11 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(con
     // 16-byte I/O: odd lanes address the neighbour pair of the NEXT register (element tid-1, +2T floats further on)
     constexpr bool WIDE = ((P / FN) / 4) % 2 == 0;
     const bool odd = WIDE && (tid & 1);
+#if ADSP_ABLATE & 64
+    const size_t chan_off = (static_cast<size_t>(c & 7) << LOGN) + 2 * tid + (odd ? 2 * T - 2 : 0);  // tuning: L2-resident I/O
+#else
     const size_t chan_off = (static_cast<size_t>(c) << LOGN) + 2 * tid + (odd ? 2 * T - 2 : 0);
+#endif
 
     // The window touches at most FN + 1 chunks.  Resolve each to a pointer once: ring history, new
     // input, or the zero page for chunks that do not exist yet / channels past the end.
@@ -685,10 +708,12 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(con
     }
 
     run_passes<PL, false, 0>(xr, xi, lds, a.tw, tid, ja, jb);
+#if !(ADSP_ABLATE & 256)
     if constexpr (PL::XL)
         spectrum_stage_xl<PL>(xr, xi, a.pair, a.pair0, tid);
     else
         spectrum_stage<PL>(xr, xi, a.pair, a.pair0, tid);
+#endif
     run_passes<PL, true, 0>(xi, xr, lds, a.tw, tid, ja, jb);  // inverse = forward on swapped parts
 
     // kept samples: circular indices [j0, j0 + keep) -> registers m_lo <= m < m_hi; register m holds

@@ -72,20 +72,18 @@ def run_passes(reg, M, P, rads, inverse, ja, jb):
 
 
 def pair_entry(H, M, k):
+    """(c1, c2, c4) of the 2x2 pairing matrix (adsp_capi.hip::pair_entry)."""
     ang = np.pi * k / M
     sc = 1.0 / (4.0 * M)
-    return complex(-np.sin(ang), -np.cos(ang)), H[k] * sc, np.conj(H[M - k]) * sc
+    wc = complex(-np.sin(ang), -np.cos(ang))
+    g1, g2 = H[k] * sc, np.conj(H[M - k]) * sc
+    s, d = g1 + g2, g1 - g2
+    return 2 * s + 2 * d * wc.real, -2j * d * wc.imag, 2 * s - 2 * d * wc.real
 
 
-def pair_op(za, zb, wc, g1, g2):
-    U = za + np.conj(zb)
-    D = za - np.conj(zb)
-    B = wc * D
-    X1, X2 = U + B, U - B
-    Pp, Q = g1 * X1, g2 * X2
-    E, Od = Pp + Q, Pp - Q
-    Op = np.conj(wc) * Od
-    return E + Op, np.conj(E - Op)
+def pair_op(za, zb, c1, c2, c4):
+    """Zy[k] = c1 Za + c2 conj(Zb);  Zy[M-k] = conj(c4 conj(Zb) - c2 Za)   (fftconv_kernel.hpp::pair_op)."""
+    return c1 * za + c2 * np.conj(zb), np.conj(c4 * np.conj(zb) - c2 * za)
 
 
 def emulate_block(window, H, M):
