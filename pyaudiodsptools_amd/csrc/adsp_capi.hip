@@ -136,7 +136,7 @@ void build_twiddles(const PlanInfo& pl, std::vector<float4>& tw) {
         int S = 1;
         for (int p = 0; p < pl.NP; ++p) {
             const int R = dir == 0 ? pl.rad[p] : pl.rad[pl.NP - 1 - p];
-            if (p > 0 && R == 16) {
+            if (p > 0 && R == 16 && S >= ADSP_TW2_MIN_S) {
                 // two-level: (w^1,w^2), (w^3,w^4), (w^8,w^12) per jlo; the kernel forms w^(4a+b) = w^(4a) w^b
                 const int qs[3][2] = {{1, 2}, {3, 4}, {8, 12}};
                 for (int h = 0; h < 3; ++h)
@@ -502,8 +502,11 @@ int adsp_apply_device(adsp_engine* e, const float* d_in, float* d_out, int n_ste
         HIP_TRY(hipMemcpyAsync(e->ring + (size_t)slot * plane, src, plane * sizeof(float), hipMemcpyDeviceToDevice, cs));
     }
     if (side) {
+        // join: everything the caller enqueues on `stream` after this call (and "stream finished => d_in may be
+        // reused") is ordered after the copy, while the copy still overlaps the kernel launched above.
         HIP_TRY(hipEventRecord(e->ev_copy_done, cs));
-        e->copy_pending = true;
+        HIP_TRY(hipStreamWaitEvent(stream, e->ev_copy_done, 0));
+        e->copy_pending = true;  // a later call on a DIFFERENT stream must also wait for it
     }
     e->ring_pos = (e->ring_pos + cnt) % S;
     return ADSP_OK;

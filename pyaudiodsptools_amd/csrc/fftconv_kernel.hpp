@@ -90,15 +90,19 @@ struct Plan {
     //  radix 16: TWO-LEVEL, 3 float4 per j_lo = (w^1,w^2), (w^3,w^4), (w^8,w^12); the other nine powers
     //            w^(4a+b) = w^(4a) * w^b are formed in registers (36 flops instead of 72 bytes of table per butterfly)
     //  other radices: (w_{2h+1}, w_{2h+2}), h < R/2.
-    static constexpr int tw_rows(int radix) { return radix == 16 ? 3 : radix / 2; }
+#ifndef ADSP_TW2_MIN_S
+#define ADSP_TW2_MIN_S 2
+#endif
+    static constexpr bool tw_two_level(int radix, int s) { return radix == 16 && s >= ADSP_TW2_MIN_S; }
+    static constexpr int tw_rows2(int radix, int s) { return tw_two_level(radix, s) ? 3 : radix / 2; }
     static constexpr int tw_count(bool inverse) {
         int n = 0;
-        for (int p = 1; p < NP_; ++p) n += tw_rows(rad(inverse, p)) * stride(inverse, p);
+        for (int p = 1; p < NP_; ++p) n += tw_rows2(rad(inverse, p), stride(inverse, p)) * stride(inverse, p);
         return n;
     }
     static constexpr int tw_offset(bool inverse, int p) {
         int n = inverse ? tw_count(false) : 0;
-        for (int i = 1; i < p; ++i) n += tw_rows(rad(inverse, i)) * stride(inverse, i);
+        for (int i = 1; i < p; ++i) n += tw_rows2(rad(inverse, i), stride(inverse, i)) * stride(inverse, i);
         return n;
     }
     static constexpr int tw_total = tw_count(false) + tw_count(true);
@@ -251,7 +255,7 @@ struct Pass {
                 ur[q] = ar[i + q * NB];
                 ui[q] = ai[i + q * NB];
             }
-            if constexpr (S > 1 && R == 16) {
+            if constexpr (S > 1 && PL::tw_two_level(R, S)) {
                 // two-level twiddles: w^(4a+b) = w^(4a) * w^b
                 const int jlo = bfly(i, tid, ja, jb) & (S - 1);
 #if ADSP_ABLATE & 1
