@@ -88,13 +88,9 @@ const PlanInfo kPlans[] = {
     make_plan<Plan<16384, 32, 4, 32, 2, 16, 16>, 1, 4>(),
 };
 
-// experimental alternatives, selected with ADSP_PLAN_VARIANT=<n> (tuning only; index into this table)
+// alternative kept for A/B measurements, selected with ADSP_PLAN_VARIANT=0 (tuning only)
 const PlanInfo kVariants[] = {
-    make_plan<Plan<4096, 16, 4, 16, 4, 8, 8>, 1, 2>(),   // 0
-    make_plan<Plan<4096, 16, 4, 16, 16, 2, 8>, 1, 2>(),  // 1
-    make_plan<Plan<4096, 16, 4, 8, 8, 8, 8>, 1, 2>(),    // 2
-    make_plan<Plan<4096, 16, 4, 4, 16, 8, 8>, 1, 2>(),   // 3
-    make_plan<Plan<4096, 32, 3, 16, 16, 16, 1>, 1, 2>(),   // 4: in-register pairing, 2 waves, 193 VGPRs
+    make_plan<Plan<4096, 32, 3, 16, 16, 16, 1>, 1, 2>(),  // 0: in-register pairing, 2 waves/transform, ~190 VGPRs
 };
 
 const PlanInfo* find_plan(int M, int FN) {

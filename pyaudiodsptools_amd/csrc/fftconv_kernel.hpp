@@ -43,6 +43,11 @@
 #define ADSP_NT 1
 #endif
 
+// ADSP_WIDE_IO: 1 = 16-byte global accesses + DPP lane-pair exchange, 0 = 8-byte accesses (tuning A/B)
+#ifndef ADSP_WIDE_IO
+#define ADSP_WIDE_IO 1
+#endif
+
 #ifndef ADSP_MIN_WAVES
 #define ADSP_MIN_WAVES 1
 #endif
@@ -547,7 +552,7 @@ __device__ __forceinline__ void load_window(const float* const (&cb)[FN + 1], fl
                                             bool odd) {
     constexpr int P = PL::P, T = PL::T, MPC = P / FN, Q = MPC / 4;
     static_assert(MPC % 4 == 0, "need at least 4 registers per chunk");
-    if constexpr (Q % 2 == 0) {
+    if constexpr (ADSP_WIDE_IO && Q % 2 == 0) {
 #pragma unroll
         for (int u = 0; u < P / 2; ++u) {
             const int gi = RQ * Q + 2 * u;  // registers 2u and 2u+1 are always in the same chunk
@@ -591,7 +596,7 @@ template <class PL, int FN, int RQ>
 __device__ __forceinline__ void store_kept(float* const (&ob)[FN + 1], const float (&xr)[PL::P],
                                            const float (&xi)[PL::P], int m_lo, int m_hi, bool odd) {
     constexpr int P = PL::P, T = PL::T, MPC = P / FN, Q = MPC / 4;
-    if constexpr (Q % 2 == 0) {
+    if constexpr (ADSP_WIDE_IO && Q % 2 == 0) {
 #pragma unroll
         for (int u = 0; u < P / 2; ++u) {
             if (2 * u >= m_lo && 2 * u < m_hi) {  // wave-uniform; kept ranges start/end on even registers
@@ -663,7 +668,7 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(con
     const int t0 = o - a.lookback;  // first input-time of the window (multiple of N/4)
     const size_t plane = static_cast<size_t>(a.C) << LOGN;  // one [C][N] chunk batch
     // 16-byte I/O: odd lanes address the neighbour pair of the NEXT register (element tid-1, +2T floats further on)
-    constexpr bool WIDE = ((P / FN) / 4) % 2 == 0;
+    constexpr bool WIDE = ADSP_WIDE_IO && ((P / FN) / 4) % 2 == 0;
     const bool odd = WIDE && (tid & 1);
 #if ADSP_ABLATE & 64
     const size_t chan_off = (static_cast<size_t>(c & 7) << LOGN) + 2 * tid + (odd ? 2 * T - 2 : 0);  // tuning: L2-resident I/O
