@@ -35,7 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
-ALG_BYTES_PER_SAMPLE = 8  # 4 B read + 4 B written, SURVEY.md 8(d)
+ALG_BYTES_PER_SAMPLE = 8  # 4 B read + 4 B written, SURVEY.md 8(d)  (float32; int16 PCM batches: 2 + 2)
 
 FILTER_NAMES = {"lowcut": "CreateLowCutFilter(800)", "highcut": "CreateHighCutFilter(8000)",
                 "eq3": "CreateEQ3BandFFT(100,2,700,-4,8000,5)",
@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--steps-per-launch", type=int, default=32)
     ap.add_argument("--ring-slots", type=int, default=8)
     ap.add_argument("--fft-mult", type=int, default=0, help="force transform length = this multiple of the chunk (0 = smallest)")
+    ap.add_argument("--io", default="f32", choices=["f32", "s16"],
+                    help="sample format of the resident batches: float32 (headline) or int16 PCM (fused WAV front end, 4 B/sample)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stream-extra", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -122,7 +124,8 @@ class Runner:
         self.C, self.N = C, N
         stream_mode = mode == "stream"
         self.bank = adist.ShardedFirBank(fir, C * world, device=local_rank,
-                                         ring_slots=args.ring_slots if stream_mode else 0, fft_mult=args.fft_mult)
+                                         ring_slots=args.ring_slots if stream_mode else 0, fft_mult=args.fft_mult,
+                                         sample_format=args.io)
         self.eng = eng = self.bank.engine
         assert eng.channels == C
         self.stream = torch.cuda.current_stream(dev)
@@ -130,15 +133,22 @@ class Runner:
         gen = torch.Generator(device=dev)
         gen.manual_seed(1234 + rank)
         amp = float(os.environ.get("ADSP_BENCH_AMPLITUDE", "1"))  # tuning only: 0 = all-zero data (DVFS check)
+        s16 = args.io == "s16"
+        dt = torch.int16 if s16 else torch.float32
+
+        def synth(shape):
+            if s16:  # uniform 16-bit PCM at -6 dBFS
+                return torch.randint(-16384, 16384, shape, device=dev, dtype=torch.int16, generator=gen)
+            return torch.empty(shape, device=dev, dtype=torch.float32).uniform_(-amp, amp, generator=gen)
         if stream_mode:
             # zero-copy streaming: the synthetic producer has filled every ring slot before the timed region
             # (apply_device copies each batch into the ring and advances it; setup only)
-            scratch = torch.empty((C, N), device=dev, dtype=torch.float32)
+            scratch = torch.empty((C, N), device=dev, dtype=dt)
             for _ in range(eng.ring_slots):
-                batch = torch.empty((C, N), device=dev, dtype=torch.float32).uniform_(-amp, amp, generator=gen)
+                batch = synth((C, N))
                 eng.apply_device(batch, scratch, 1, sptr)
                 torch.cuda.synchronize(dev)
-            self.outs = [torch.empty((C, N), device=dev, dtype=torch.float32) for _ in range(4)]
+            self.outs = [torch.empty((C, N), device=dev, dtype=dt) for _ in range(4)]
             self.spl = 1
 
             def run(k_steps):
@@ -148,9 +158,8 @@ class Runner:
             self.spl = spl = args.steps_per_launch
             # distinct resident input batches, > 256 MiB in total so the Infinity Cache cannot hold them
             n_in = max(2, min(8, -(-(768 << 20) // (spl * C * N * 4))))
-            self.ins = [torch.empty((spl, C, N), device=dev, dtype=torch.float32).uniform_(-amp, amp, generator=gen)
-                        for _ in range(n_in)]
-            self.outs = [torch.empty((spl, C, N), device=dev, dtype=torch.float32) for _ in range(2)]
+            self.ins = [synth((spl, C, N)) for _ in range(n_in)]
+            self.outs = [torch.empty((spl, C, N), device=dev, dtype=dt) for _ in range(2)]
 
             def run(k_steps):
                 for i in range(k_steps // spl):
@@ -176,7 +185,7 @@ class Runner:
         torch.cuda.synchronize()
         kern_ms, launches = eng.kernel_time()
         eng.enable_kernel_timing(False)
-        chk = self.outs[0].reshape(-1)[:: max(1, self.outs[0].numel() // 65536)]
+        chk = self.outs[0].reshape(-1)[:: max(1, self.outs[0].numel() // 65536)].float()
         assert bool(torch.isfinite(chk).all()) and (float(chk.abs().max()) > 0 or os.environ.get("ADSP_BENCH_AMPLITUDE") == "0")
         return steps, warm, wall, kern_ms, launches
 
@@ -204,6 +213,7 @@ def main():
 
     fir = make_fir(args)
     C, N = args.channels, args.chunk
+    alg_bytes = ALG_BYTES_PER_SAMPLE if args.io == "f32" else 4
     main_run = Runner(args, args.mode, fir, dev, local_rank, world, rank)
     steps, warm, wall, kern_ms, launches = main_run.measure(args.steps, args.warmup, barrier)
     if world > 1:
@@ -220,7 +230,7 @@ def main():
         s_per = s_kern_ms / 1e3 / s_launches
         extra_stream = {"value": round(C * N * s_steps / s_wall / 1e6, 1), "unit": "Msamples/s", "steps": s_steps,
                         "avg_kernel_us": round(s_per * 1e6, 2),
-                        "roofline_frac": round(ALG_BYTES_PER_SAMPLE * C * N / s_per / 1e9 / HBM_PEAK_GBS, 4),
+                        "roofline_frac": round(alg_bytes * C * N / s_per / 1e9 / HBM_PEAK_GBS, 4),
                         "note": "one launch per step through the zero-copy ring (adsp_apply_ring), N outputs kept per 2N transform"}
 
     if rank == 0:
@@ -228,19 +238,19 @@ def main():
         value = C * N * world * steps / wall / 1e6
         per_launch_s = kern_ms / 1e3 / launches
         samples_per_launch = C * N * (steps // launches)
-        achieved = ALG_BYTES_PER_SAMPLE * samples_per_launch / per_launch_s / 1e9
+        achieved = alg_bytes * samples_per_launch / per_launch_s / 1e9
         mode_key = "stream" if args.mode == "stream" else "batch"
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
-                rec = json.load(open(tf)).get(f"{args.filter}_{C}x{N}_{mode_key}")
+                rec = json.load(open(tf)).get(f"{args.filter}_{C}x{N}_{mode_key}" + ("" if args.io == "f32" else "_s16"))
                 if rec and rec.get("steps_per_launch", main_run.spl) == main_run.spl:
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
-            "metric": f"Msamples/s (float32, {N}-pt OLA FFT filter)",
+            "metric": f"Msamples/s ({'float32' if args.io == 'f32' else 'int16 PCM'}, {N}-pt OLA FFT filter)",
             "value": round(value, 1),
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -250,8 +260,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic uniform(-1,1) float32 resident in HBM " +
+            "dtype": "f32" if args.io == "f32" else "f32 arithmetic on s16 samples",
+            "data": ("synthetic uniform(-1,1) float32" if args.io == "f32" else "synthetic uniform int16 PCM (-6 dBFS)") + " resident in HBM " +
                     ("(library input ring)" if args.mode == "stream" else "([steps, channels, chunk] batches)"),
             "config": {"workload": f"{FILTER_NAMES[args.filter]} @ {args.fs} Hz, {C} mono channels x {N}-sample chunks per GPU",
                        "channels_per_gpu": C, "chunk_size": N, "mode": mode_key, "steps_per_launch": main_run.spl,
@@ -261,7 +271,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "adsp::fftconv_kernel", "avg_launch_us": round(per_launch_s * 1e6, 2),
-                         "launches": launches, "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * samples_per_launch},
+                         "launches": launches, "algorithmic_bytes_per_launch": alg_bytes * samples_per_launch},
         }
         if extra_stream:
             line["stream"] = extra_stream

@@ -22,8 +22,9 @@
  *     EffectFFTFilter.py:63-65); distinct engines are independent.
  *   - the library owns all device memory it allocates; "d_" pointers are caller-owned device
  *     memory, all others are host memory.
- *   - batch layout everywhere: [step][channel][sample] row-major float32, i.e. the chunk of
- *     channel c at step k starts at ((k * n_channels) + c) * chunk_size.
+ *   - batch layout everywhere: [step][channel][sample] row-major, samples in the engine's
+ *     sample_format (float32 or int16), i.e. the chunk of channel c at step k starts at sample
+ *     ((k * n_channels) + c) * chunk_size.  Device buffers must be 16-byte aligned.
  */
 #ifndef ADSP_H
 #define ADSP_H
@@ -38,7 +39,7 @@ extern "C" {
 #define ADSP_API
 #endif
 
-#define ADSP_ABI_VERSION 1
+#define ADSP_ABI_VERSION 2
 #define ADSP_MAX_HISTORY 8
 
 typedef enum adsp_status {
@@ -50,6 +51,12 @@ typedef enum adsp_status {
 } adsp_status;
 
 typedef struct adsp_engine adsp_engine; /* opaque */
+
+/* Sample formats of the [step][channel][sample] batches an engine filters (adsp_config.sample_format). */
+#define ADSP_FORMAT_F32 0 /* float32, the reference's in-memory format */
+#define ADSP_FORMAT_S16 1 /* int16 PCM, the reference's WAV format: the kernel converts (float)x on load and
+                             (int16)trunc(y) on store - Utility.py:233-238 (/32768) and :295-312 (*32767,
+                             astype int16) become ONE factor 32767/32768 folded into the spectrum by the host */
 
 /*
  * Geometry of one streaming FIR engine.
@@ -74,6 +81,7 @@ typedef struct adsp_config {
     int out_offset;      /* see above */
     int ring_slots;      /* input ring length (>= history_chunks+1); 0 = 2*history_chunks, which lets the ring
                             update of multi-step launches run on a side stream beside the kernel */
+    int sample_format;   /* ADSP_FORMAT_F32 or ADSP_FORMAT_S16: type of every `in`/`out`/ring/state buffer below */
 } adsp_config;
 
 /* ABI version (ADSP_ABI_VERSION of the built library). */
@@ -115,25 +123,25 @@ ADSP_API int adsp_set_block_outputs(adsp_engine* engine, int block_outputs);
 /* Forget all history (a fresh reference device). */
 ADSP_API int adsp_reset(adsp_engine* engine);
 
-/* The reference's apply() on host buffers, batched: in/out are [n_steps][C][N] float32 host arrays
- * (in is only read, out is fully overwritten).  H2D -> kernel -> D2H, synchronous on return. */
-ADSP_API int adsp_apply_host(adsp_engine* engine, const float* in, float* out, int n_steps);
+/* The reference's apply() on host buffers, batched: in/out are [n_steps][C][N] host arrays
+ * (in is only read, out is fully overwritten) of the engine's sample type.  H2D -> kernel -> D2H, synchronous. */
+ADSP_API int adsp_apply_host(adsp_engine* engine, const void* in, void* out, int n_steps);
 
 /* The measured path: device-resident [n_steps][C][N] batches, asynchronous on `stream`
  * (a hipStream_t passed as void*; NULL = the default stream).  d_in must stay unmodified until the
  * work on `stream` has finished.  History is carried inside the engine between calls. */
-ADSP_API int adsp_apply_device(adsp_engine* engine, const float* d_in, float* d_out, int n_steps, void* stream);
+ADSP_API int adsp_apply_device(adsp_engine* engine, const void* d_in, void* d_out, int n_steps, void* stream);
 
 /* Zero-copy streaming: the producer (H2D copy, decoder, generator kernel) writes the next chunk
  * batch [C][N] straight into the ring slot returned by adsp_ring_acquire, then adsp_apply_ring
  * filters it.  No state copy, 1.25-1.75 N reads + N writes per channel per step. */
-ADSP_API int adsp_ring_acquire(adsp_engine* engine, float** d_slot);
-ADSP_API int adsp_apply_ring(adsp_engine* engine, float* d_out, void* stream);
+ADSP_API int adsp_ring_acquire(adsp_engine* engine, void** d_slot);
+ADSP_API int adsp_apply_ring(adsp_engine* engine, void* d_out, void* stream);
 
 /* Test hooks: the engine's history as [history_chunks][C][N] host floats, oldest first
  * (the reference's float32_array_input_3/_2). */
-ADSP_API int adsp_get_state(adsp_engine* engine, float* host_history);
-ADSP_API int adsp_set_state(adsp_engine* engine, const float* host_history);
+ADSP_API int adsp_get_state(adsp_engine* engine, void* host_history);
+ADSP_API int adsp_set_state(adsp_engine* engine, const void* host_history);
 
 /* Kernel timing for benchmarks: when enabled, every launch of the filter kernel is bracketed by a pair
  * of HIP events recorded on the launch stream (the kernel only - not the history copy that follows a

@@ -276,3 +276,23 @@ def make_chunks(signal: np.ndarray, chunk_size: int):
 def combine_chunks(chunks):
     """Utility.py:45-48 (without the O(n^2) append)."""
     return np.concatenate([np.asarray(c, dtype="float32") for c in chunks]) if len(chunks) else np.array([], "float32")
+
+
+# --------------------------------------------------------------------------------------
+# 16-bit PCM front end (SURVEY 8f.1): what Example1.py / Example2.py do around the devices
+# --------------------------------------------------------------------------------------
+def pcm16_to_float(pcm):
+    """Utility.py:236-237: int16 -> float32 / 32768."""
+    return np.asarray(pcm, dtype=np.int16).astype("float32") / 32768
+
+
+def float_to_pcm16(x):
+    """Utility.py:306: (x * 32767).astype('int16') (truncation toward zero)."""
+    return (np.asarray(x) * 32767).astype("int16")
+
+
+def run_device_pcm16(device, pcm, chunk_size):
+    """int16 stream in, int16 stream out through a float device, chunk by chunk (Example1.py:6-22)."""
+    x = pcm16_to_float(pcm)
+    y = np.concatenate([device.apply(x[i * chunk_size:(i + 1) * chunk_size]) for i in range(len(x) // chunk_size)])
+    return float_to_pcm16(y)

@@ -14,7 +14,12 @@ from .design import FirStream
 from .devices import (CreateEQ3BandFFT, CreateEQ3BandFFTGPU, CreateHighCutFilter, CreateHighCutFilterGPU,
                       CreateLowCutFilter, CreateLowCutFilterGPU, fuse)
 from .engine import FirEngine
+from . import wavio as Utility
+from .wavio import (CombineChunks, MakeChunks, MonoWavToNumpy16BitInt, MonoWavToNumpyFloat, NumpyFloatToWav,
+                    StereoWavToNumpyFloat, WavBank)
 
 __all__ = ["config", "CreateHighCutFilter", "CreateLowCutFilter", "CreateEQ3BandFFT", "CreateHighCutFilterGPU",
-           "CreateLowCutFilterGPU", "CreateEQ3BandFFTGPU", "FirEngine", "FirStream", "fuse"]
+           "CreateLowCutFilterGPU", "CreateEQ3BandFFTGPU", "FirEngine", "FirStream", "fuse", "Utility", "MakeChunks",
+           "CombineChunks", "MonoWavToNumpyFloat", "MonoWavToNumpy16BitInt", "StereoWavToNumpyFloat", "NumpyFloatToWav",
+           "WavBank"]
 __version__ = "0.1.0"

@@ -6,8 +6,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADSP_LIB") or os.path.join(_HERE, "libadsp.so")  # ADSP_LIB: tuning builds only
 
-ADSP_ABI_VERSION = 1
+ADSP_ABI_VERSION = 2
 ADSP_MAX_HISTORY = 8
+ADSP_FORMAT_F32, ADSP_FORMAT_S16 = 0, 1
 ADSP_OK, ADSP_ERR_ARG, ADSP_ERR_HIP, ADSP_ERR_STATE, ADSP_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 
 
@@ -27,6 +28,7 @@ class AdspConfig(ctypes.Structure):
         ("lookback", ctypes.c_int),
         ("out_offset", ctypes.c_int),
         ("ring_slots", ctypes.c_int),
+        ("sample_format", ctypes.c_int),
     ]
 
 

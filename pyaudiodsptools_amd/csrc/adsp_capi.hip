@@ -14,7 +14,7 @@
 #include <vector>
 
 #include "../../include/adsp.h"
-#include "fftconv_kernel.hpp"
+#include "plan_table.hpp"
 
 namespace {
 
@@ -37,70 +37,20 @@ int fail(int code, const char* fmt, ...) {
             return fail(ADSP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
     } while (0)
 
-// ------------------------------------------------------------------------------------------
-// plan registry
-// ------------------------------------------------------------------------------------------
-struct PlanInfo {
-    int M, FN, P, T, CPB, NP, XL;  // FN = fft_size / chunk_size; XL = cross-lane pairing plan
-    int rad[4];
-    int tw_total;
-    int lds_bytes;
-    hipError_t (*launch)(const adsp::KernelArgs&, int grid, hipStream_t);
-    hipError_t (*prepare)();
-};
+using adsp::PlanInfo;
 
-template <class PL, int CPB, int FN>
-hipError_t launch_impl(const adsp::KernelArgs& a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((adsp::fftconv_kernel<PL, CPB, FN>), dim3(grid), dim3(PL::T * CPB), PL::M * CPB * sizeof(float2), s, a);
-    return hipGetLastError();
-}
-
-template <class PL, int CPB, int FN>
-hipError_t prepare_impl() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&adsp::fftconv_kernel<PL, CPB, FN>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, PL::M * CPB * (int)sizeof(float2));
-}
-
-template <class PL, int CPB, int FN>
-constexpr PlanInfo make_plan() {
-    return PlanInfo{PL::M, FN, PL::P, PL::T, CPB, PL::NP, PL::XL ? 1 : 0, {PL::fwd(0), PL::fwd(1), PL::fwd(2), PL::fwd(3)},
-                    PL::tw_total, PL::M * CPB * (int)sizeof(float2), &launch_impl<PL, CPB, FN>, &prepare_impl<PL, CPB, FN>};
-}
-
-using adsp::Plan;
-// M (complex points) -> plan.  Last forward radix is always P/2 (see fftconv_kernel.hpp).
-const PlanInfo kPlans[] = {
-    make_plan<Plan<64, 16, 2, 8, 8, 1, 1>, 16, 2>(),
-    make_plan<Plan<128, 16, 2, 16, 8, 1, 1>, 8, 2>(),
-    make_plan<Plan<128, 16, 2, 16, 8, 1, 1>, 8, 4>(),
-    make_plan<Plan<256, 16, 3, 4, 8, 8, 1>, 4, 2>(),
-    make_plan<Plan<256, 16, 3, 4, 8, 8, 1>, 4, 4>(),
-    make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 2, 2>(),
-    make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 2, 4>(),
-    make_plan<Plan<1024, 16, 3, 16, 8, 8, 1>, 1, 2>(),
-    make_plan<Plan<1024, 16, 3, 16, 8, 8, 1>, 1, 4>(),
-    make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 2>(),
-    make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 4>(),
-    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 2>(),  // cross-lane pairing: 4 waves, 96 VGPRs
-    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 4>(),
-    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1, 2>(),
-    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1, 4>(),
-    make_plan<Plan<16384, 32, 4, 32, 2, 16, 16>, 1, 4>(),
-};
-
-// alternative kept for A/B measurements, selected with ADSP_PLAN_VARIANT=0 (tuning only)
-const PlanInfo kVariants[] = {
-    make_plan<Plan<4096, 32, 3, 16, 16, 16, 1>, 1, 2>(),  // 0: in-register pairing, 2 waves/transform, ~190 VGPRs
-};
-
-const PlanInfo* find_plan(int M, int FN) {
-    if (const char* v = getenv("ADSP_PLAN_VARIANT")) {
-        const int i = atoi(v);
-        if (i >= 0 && i < (int)(sizeof(kVariants) / sizeof(kVariants[0])) && kVariants[i].M == M && kVariants[i].FN == FN)
-            return &kVariants[i];
+const PlanInfo* find_plan(int M, int FN, int fmt) {
+    int n = 0;
+    if (fmt == ADSP_FORMAT_F32) {
+        if (const char* v = getenv("ADSP_PLAN_VARIANT")) {
+            const PlanInfo* var = adsp::variants_f32(&n);
+            const int i = atoi(v);
+            if (i >= 0 && i < n && var[i].M == M && var[i].FN == FN) return &var[i];
+        }
     }
-    for (const PlanInfo& p : kPlans)
-        if (p.M == M && p.FN == FN) return &p;
+    const PlanInfo* tab = fmt == ADSP_FORMAT_S16 ? adsp::plans_s16(&n) : adsp::plans_f32(&n);
+    for (int i = 0; i < n; ++i)
+        if (tab[i].M == M && tab[i].FN == FN) return &tab[i];
     return nullptr;
 }
 
@@ -111,10 +61,11 @@ int ilog2(int v) {
     return l;
 }
 
-int check_geometry(int N, int F, const PlanInfo** out) {
+int check_geometry(int N, int F, int fmt, const PlanInfo** out) {
     if (!is_pow2(N) || N < 64 || N > 8192) return fail(ADSP_ERR_ARG, "chunk_size %d: need a power of two in 64..8192", N);
     if (F != 2 * N && F != 4 * N) return fail(ADSP_ERR_ARG, "fft_size %d: need 2*chunk_size or 4*chunk_size", F);
-    const PlanInfo* p = find_plan(F / 2, F / N);
+    if (fmt != ADSP_FORMAT_F32 && fmt != ADSP_FORMAT_S16) return fail(ADSP_ERR_ARG, "sample_format %d: need ADSP_FORMAT_F32 or ADSP_FORMAT_S16", fmt);
+    const PlanInfo* p = find_plan(F / 2, F / N, fmt);
     if (!p) return fail(ADSP_ERR_ARG, "no kernel plan for %d complex points", F / 2);
     if (out) *out = p;
     return ADSP_OK;
@@ -181,23 +132,25 @@ struct adsp_engine {
     adsp_config cfg;
     const PlanInfo* plan;
     int M, logN, block_outputs;
-    float* ring;   // [ring_slots][C][N]
+    char* ring;    // [ring_slots][C][N] samples of cfg.sample_format
     int ring_pos;  // slot of the most recent chunk
     float4* tw;
     float4* pair;
     float2* pair0;
-    float* zeros;  // chunk_size zero floats
+    char* zeros;   // 4*chunk_size zero bytes
     bool have_spectrum;
-    float* stage_in;
-    float* stage_out;
-    size_t stage_elems;
+    char* stage_in;
+    char* stage_out;
+    size_t stage_elems;  // capacity in samples
     bool timing;
     hipStream_t copy_stream;  // ring update of multi-step launches runs beside the kernel
     hipEvent_t ev_in_ready, ev_copy_done;
     bool copy_pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;   // recorded, not yet read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_ev;  // recycled event pairs
-    size_t plane() const { return (size_t)cfg.n_channels * (size_t)cfg.chunk_size; }
+    size_t plane() const { return (size_t)cfg.n_channels * (size_t)cfg.chunk_size; }                 // samples per chunk batch
+    size_t ssize() const { return cfg.sample_format == ADSP_FORMAT_S16 ? sizeof(short) : sizeof(float); }  // bytes per sample
+    size_t plane_bytes() const { return plane() * ssize(); }
 };
 
 namespace {
@@ -248,7 +201,7 @@ int upload_pairs(adsp_engine* e, const float* H, hipStream_t stream) {
     return ADSP_OK;
 }
 
-int launch(adsp_engine* e, const float* d_in, float* d_out, int n_steps, hipStream_t stream) {
+int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream_t stream) {
     const adsp_config& c = e->cfg;
     const PlanInfo& pl = *e->plan;
     adsp::KernelArgs a;
@@ -312,12 +265,12 @@ int adsp_device_count(int* count) {
     return ADSP_OK;
 }
 
-int adsp_plan_supported(int chunk_size, int fft_size) { return check_geometry(chunk_size, fft_size, nullptr); }
+int adsp_plan_supported(int chunk_size, int fft_size) { return check_geometry(chunk_size, fft_size, ADSP_FORMAT_F32, nullptr); }
 
 int adsp_plan_describe(int chunk_size, int fft_size, int* complex_points, int* points_per_thread,
                        int* threads_per_transform, int* channels_per_workgroup, int* lds_bytes) {
     const PlanInfo* p = nullptr;
-    int rc = check_geometry(chunk_size, fft_size, &p);
+    int rc = check_geometry(chunk_size, fft_size, ADSP_FORMAT_F32, &p);
     if (rc) return rc;
     if (complex_points) *complex_points = p->M;
     if (points_per_thread) *points_per_thread = p->P;
@@ -331,7 +284,7 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     if (!cfg || !out_engine) return fail(ADSP_ERR_ARG, "NULL argument");
     *out_engine = nullptr;
     const PlanInfo* pl = nullptr;
-    int rc = check_geometry(cfg->chunk_size, cfg->fft_size, &pl);
+    int rc = check_geometry(cfg->chunk_size, cfg->fft_size, cfg->sample_format, &pl);
     if (rc) return rc;
     const int N = cfg->chunk_size, F = cfg->fft_size, T2 = 2 * pl->T;
     if (cfg->n_channels <= 0) return fail(ADSP_ERR_ARG, "n_channels must be positive");
@@ -381,7 +334,7 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     if ((rc = set_device(e))) return bail(rc);
     hipError_t err;
     if ((err = pl->prepare()) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(err)));
-    const size_t ring_bytes = (size_t)slots * e->plane() * sizeof(float);
+    const size_t ring_bytes = (size_t)slots * e->plane_bytes();
     if ((err = hipMalloc(&e->ring, ring_bytes)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc ring (%zu bytes): %s", ring_bytes, hipGetErrorString(err)));
     if ((err = hipMemset(e->ring, 0, ring_bytes)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMemset: %s", hipGetErrorString(err)));
     std::vector<float4> tw;
@@ -465,12 +418,12 @@ int adsp_reset(adsp_engine* e) {
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     e->copy_pending = false;
-    HIP_TRY(hipMemset(e->ring, 0, (size_t)e->cfg.ring_slots * e->plane() * sizeof(float)));
+    HIP_TRY(hipMemset(e->ring, 0, (size_t)e->cfg.ring_slots * e->plane_bytes()));
     e->ring_pos = e->cfg.ring_slots - 1;
     return ADSP_OK;
 }
 
-int adsp_apply_device(adsp_engine* e, const float* d_in, float* d_out, int n_steps, void* stream_v) {
+int adsp_apply_device(adsp_engine* e, const void* d_in, void* d_out, int n_steps, void* stream_v) {
     if (!e || !d_in || !d_out) return fail(ADSP_ERR_ARG, "NULL argument");
     if (n_steps <= 0) return fail(ADSP_ERR_ARG, "n_steps must be positive");
     if (!e->have_spectrum) return fail(ADSP_ERR_STATE, "adsp_set_spectrum has not been called");
@@ -479,7 +432,7 @@ int adsp_apply_device(adsp_engine* e, const float* d_in, float* d_out, int n_ste
     hipStream_t stream = (hipStream_t)stream_v;
     const int S = e->cfg.ring_slots;
     const int cnt = n_steps < e->cfg.history_chunks ? n_steps : e->cfg.history_chunks;
-    const size_t plane = e->plane();
+    const size_t plane = e->plane_bytes();
     // The newest `cnt` chunks must end up in the ring.  They go to slots the kernel does not read when the ring has
     // >= 2*history slots, so the copy can run on a side stream BESIDE the kernel: it waits for the caller's input
     // (event on `stream` before the launch) and the next launch on any stream waits for it (event after the copy).
@@ -494,8 +447,8 @@ int adsp_apply_device(adsp_engine* e, const float* d_in, float* d_out, int n_ste
     if (side) HIP_TRY(hipStreamWaitEvent(cs, e->ev_in_ready, 0));
     for (int i = 0; i < cnt; ++i) {
         const int slot = (e->ring_pos + 1 + i) % S;
-        const float* src = d_in + (size_t)(n_steps - cnt + i) * plane;
-        HIP_TRY(hipMemcpyAsync(e->ring + (size_t)slot * plane, src, plane * sizeof(float), hipMemcpyDeviceToDevice, cs));
+        const char* src = static_cast<const char*>(d_in) + (size_t)(n_steps - cnt + i) * plane;
+        HIP_TRY(hipMemcpyAsync(e->ring + (size_t)slot * plane, src, plane, hipMemcpyDeviceToDevice, cs));
     }
     if (side) {
         // join: everything the caller enqueues on `stream` after this call (and "stream finished => d_in may be
@@ -508,14 +461,14 @@ int adsp_apply_device(adsp_engine* e, const float* d_in, float* d_out, int n_ste
     return ADSP_OK;
 }
 
-int adsp_ring_acquire(adsp_engine* e, float** d_slot) {
+int adsp_ring_acquire(adsp_engine* e, void** d_slot) {
     if (!e || !d_slot) return fail(ADSP_ERR_ARG, "NULL argument");
     const int slot = (e->ring_pos + 1) % e->cfg.ring_slots;
-    *d_slot = e->ring + (size_t)slot * e->plane();
+    *d_slot = e->ring + (size_t)slot * e->plane_bytes();
     return ADSP_OK;
 }
 
-int adsp_apply_ring(adsp_engine* e, float* d_out, void* stream_v) {
+int adsp_apply_ring(adsp_engine* e, void* d_out, void* stream_v) {
     if (!e || !d_out) return fail(ADSP_ERR_ARG, "NULL argument");
     if (!e->have_spectrum) return fail(ADSP_ERR_STATE, "adsp_set_spectrum has not been called");
     int rc = set_device(e);
@@ -525,12 +478,12 @@ int adsp_apply_ring(adsp_engine* e, float* d_out, void* stream_v) {
         e->copy_pending = false;
     }
     const int slot = (e->ring_pos + 1) % e->cfg.ring_slots;
-    if ((rc = launch(e, e->ring + (size_t)slot * e->plane(), d_out, 1, (hipStream_t)stream_v))) return rc;
+    if ((rc = launch(e, e->ring + (size_t)slot * e->plane_bytes(), d_out, 1, (hipStream_t)stream_v))) return rc;
     e->ring_pos = slot;
     return ADSP_OK;
 }
 
-int adsp_apply_host(adsp_engine* e, const float* in, float* out, int n_steps) {
+int adsp_apply_host(adsp_engine* e, const void* in, void* out, int n_steps) {
     if (!e || !in || !out) return fail(ADSP_ERR_ARG, "NULL argument");
     if (n_steps <= 0) return fail(ADSP_ERR_ARG, "n_steps must be positive");
     int rc = set_device(e);
@@ -542,41 +495,41 @@ int adsp_apply_host(adsp_engine* e, const float* in, float* out, int n_steps) {
         if (e->stage_out) (void)hipFree(e->stage_out);
         e->stage_in = e->stage_out = nullptr;
         e->stage_elems = 0;
-        HIP_TRY(hipMalloc(&e->stage_in, elems * sizeof(float)));
-        HIP_TRY(hipMalloc(&e->stage_out, elems * sizeof(float)));
+        HIP_TRY(hipMalloc(&e->stage_in, elems * e->ssize()));
+        HIP_TRY(hipMalloc(&e->stage_out, elems * e->ssize()));
         e->stage_elems = elems;
     }
-    HIP_TRY(hipMemcpy(e->stage_in, in, elems * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->stage_in, in, elems * e->ssize(), hipMemcpyHostToDevice));
     if ((rc = adsp_apply_device(e, e->stage_in, e->stage_out, n_steps, nullptr))) return rc;
-    HIP_TRY(hipMemcpy(out, e->stage_out, elems * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, e->stage_out, elems * e->ssize(), hipMemcpyDeviceToHost));
     return ADSP_OK;
 }
 
-int adsp_get_state(adsp_engine* e, float* host_history) {
+int adsp_get_state(adsp_engine* e, void* host_history) {
     if (!e || !host_history) return fail(ADSP_ERR_ARG, "NULL argument");
     int rc = set_device(e);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     e->copy_pending = false;
     const int S = e->cfg.ring_slots, nh = e->cfg.history_chunks;
-    const size_t plane = e->plane();
+    const size_t plane = e->plane_bytes();
     for (int h = 0; h < nh; ++h) {  // h = 0 oldest (time step -nh)
         const int slot = ((e->ring_pos + 1 - nh + h) % S + S) % S;
-        HIP_TRY(hipMemcpy(host_history + (size_t)h * plane, e->ring + (size_t)slot * plane, plane * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(static_cast<char*>(host_history) + (size_t)h * plane, e->ring + (size_t)slot * plane, plane, hipMemcpyDeviceToHost));
     }
     return ADSP_OK;
 }
 
-int adsp_set_state(adsp_engine* e, const float* host_history) {
+int adsp_set_state(adsp_engine* e, const void* host_history) {
     if (!e || !host_history) return fail(ADSP_ERR_ARG, "NULL argument");
     int rc = set_device(e);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     const int S = e->cfg.ring_slots, nh = e->cfg.history_chunks;
-    const size_t plane = e->plane();
+    const size_t plane = e->plane_bytes();
     for (int h = 0; h < nh; ++h) {
         const int slot = ((e->ring_pos + 1 - nh + h) % S + S) % S;
-        HIP_TRY(hipMemcpy(e->ring + (size_t)slot * plane, host_history + (size_t)h * plane, plane * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->ring + (size_t)slot * plane, static_cast<const char*>(host_history) + (size_t)h * plane, plane, hipMemcpyHostToDevice));
     }
     return ADSP_OK;
 }

@@ -29,6 +29,7 @@
 //    write bandwidth and fp32 VALU in that order.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <utility>
 
 // ADSP_ABLATE: tuning-only bitmask that removes one ingredient of the kernel to see what it costs
@@ -55,13 +56,13 @@
 namespace adsp {
 
 struct KernelArgs {
-    const float* ring;     // [ring_slots][C][N] input history ring
-    const float* in;       // [n_steps][C][N] new input (may point into the ring)
-    float* out;            // [n_steps][C][N]
+    const void* ring;      // [ring_slots][C][N] input history ring   (float32 or int16 samples, see S16)
+    const void* in;        // [n_steps][C][N] new input (may point into the ring)
+    void* out;             // [n_steps][C][N]
     const float4* tw;      // pass twiddles as (w_odd, w_even) pairs: forward passes 1.., then inverse passes 1..
     const float4* pair;    // [R/2][3][T] float4: (wc,g1)_r, (g2_r,wc_r+1), (g1,g2)_r+1 for threads 1..T-1
     const float2* pair0;   // [R+1][3]   thread 0's self-paired butterflies
-    const float* zeros;    // >= N zero floats (stands in for chunks that do not exist)
+    const void* zeros;     // >= 4N zero bytes (stands in for chunks that do not exist)
     int ring_pos;          // slot holding the most recent history chunk (time step -1)
     int ring_slots;
     int C;                 // channels
@@ -637,9 +638,86 @@ __device__ __forceinline__ void store_kept(float* const (&ob)[FN + 1], const flo
 }
 
 // ------------------------------------------------------------------------------------------
+// int16 PCM samples (the reference's WAV front end, Utility.py:233-238 and :295-312, fused into
+// the filter).  An element z[n] = (x[2n], x[2n+1]) is ONE dword; input conversion is (float)int16 and output
+// conversion (int16)trunc(y) - the /32768 and *32767 of the reference are folded into the spectrum by the host.
+// Same lane-pair trick as above with 8-byte accesses (two elements).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned lane_xor1_u(unsigned v) {
+    return __builtin_amdgcn_update_dpp(0u, v, 0xB1, 0xF, 0xF, true);
+}
+__device__ __forceinline__ void unpack_s16(unsigned w, float& re, float& im) {
+    re = static_cast<float>(static_cast<int>(static_cast<short>(w & 0xffffu)));
+    im = static_cast<float>(static_cast<int>(w) >> 16);
+}
+__device__ __forceinline__ unsigned pack_s16(float re, float im) {
+    // (numpy_array * 32767).astype('int16'): truncation toward zero (v_cvt_i32_f32), low 16 bits kept
+    const unsigned a = static_cast<unsigned>(static_cast<int>(re)) & 0xffffu;
+    const unsigned b = static_cast<unsigned>(static_cast<int>(im)) << 16;
+    return a | b;
+}
+
+template <class PL, int FN, int RQ>
+__device__ __forceinline__ void load_window_s16(const unsigned* const (&cb)[FN + 1], float (&xr)[PL::P],
+                                                float (&xi)[PL::P], bool odd) {
+    constexpr int P = PL::P, T = PL::T, MPC = P / FN, Q = MPC / 4;
+    if constexpr (ADSP_WIDE_IO && Q % 2 == 0) {
+#pragma unroll
+        for (int u = 0; u < P / 2; ++u) {
+            const int gi = RQ * Q + 2 * u;
+            const int i = gi / MPC;
+            const int off = (gi % MPC) * T;  // dwords
+            const uint2 v = *reinterpret_cast<const uint2*>(cb[i] + off);
+            const unsigned sx = lane_xor1_u(odd ? v.x : v.y);
+            unpack_s16(odd ? sx : v.x, xr[2 * u], xi[2 * u]);
+            unpack_s16(odd ? v.y : sx, xr[2 * u + 1], xi[2 * u + 1]);
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < P; ++m) {
+            const int gi = RQ * Q + m;
+            const int i = gi / MPC;
+            const int off = (gi % MPC) * T;
+            unpack_s16(cb[i][off], xr[m], xi[m]);
+        }
+    }
+}
+
+template <class PL, int FN, int RQ>
+__device__ __forceinline__ void store_kept_s16(unsigned* const (&ob)[FN + 1], const float (&xr)[PL::P],
+                                               const float (&xi)[PL::P], int m_lo, int m_hi, bool odd) {
+    constexpr int P = PL::P, T = PL::T, MPC = P / FN, Q = MPC / 4;
+    if constexpr (ADSP_WIDE_IO && Q % 2 == 0) {
+#pragma unroll
+        for (int u = 0; u < P / 2; ++u) {
+            if (2 * u >= m_lo && 2 * u < m_hi) {
+                const int gi = RQ * Q + 2 * u;
+                const int i = gi / MPC;
+                const int off = (gi % MPC) * T;
+                const unsigned w0 = pack_s16(xr[2 * u], xi[2 * u]), w1 = pack_s16(xr[2 * u + 1], xi[2 * u + 1]);
+                const unsigned sx = lane_xor1_u(odd ? w0 : w1);
+                typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                const v2u v = odd ? v2u{sx, w1} : v2u{w0, sx};
+                __builtin_nontemporal_store(v, reinterpret_cast<v2u*>(ob[i] + off));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < P; ++m) {
+            if (m >= m_lo && m < m_hi) {
+                const int gi = RQ * Q + m;
+                const int i = gi / MPC;
+                const int off = (gi % MPC) * T;
+                ob[i][off] = pack_s16(xr[m], xi[m]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // the kernel: one workgroup = CPB channels x one time block
 // ------------------------------------------------------------------------------------------
-template <class PL, int CPB, int FN>
+template <class PL, int CPB, int FN, bool S16 = false>
 __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(const KernelArgs a) {
     constexpr int M = PL::M, P = PL::P, T = PL::T;
     constexpr int N = 2 * M / FN;  // chunk size
@@ -666,43 +744,56 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(con
 
     const int o = blk * a.V;        // first output-time of this block (multiple of N/4)
     const int t0 = o - a.lookback;  // first input-time of the window (multiple of N/4)
-    const size_t plane = static_cast<size_t>(a.C) << LOGN;  // one [C][N] chunk batch
-    // 16-byte I/O: odd lanes address the neighbour pair of the NEXT register (element tid-1, +2T floats further on)
+    // Sample storage unit U: float (2 per element) or, for int16 PCM, one dword per element.
+    using U = typename std::conditional<S16, unsigned, float>::type;
+    constexpr int UPE = S16 ? 1 : 2;                                        // units per complex element
+    const size_t plane = (static_cast<size_t>(a.C) << LOGN) / 2 * UPE;      // one [C][N] chunk batch, in units
+    // wide I/O: odd lanes address the neighbour pair of the NEXT register (element tid-1, one register = T elements on)
     constexpr bool WIDE = ADSP_WIDE_IO && ((P / FN) / 4) % 2 == 0;
     const bool odd = WIDE && (tid & 1);
+    const size_t lane_off = static_cast<size_t>(UPE) * (tid + (odd ? T - 1 : 0));
 #if ADSP_ABLATE & 64
-    const size_t chan_off = (static_cast<size_t>(c & 7) << LOGN) + 2 * tid + (odd ? 2 * T - 2 : 0);  // tuning: L2-resident I/O
+    const size_t chan_off = (static_cast<size_t>(c & 7) << LOGN) / 2 * UPE + lane_off;  // tuning: L2-resident I/O
 #else
-    const size_t chan_off = (static_cast<size_t>(c) << LOGN) + 2 * tid + (odd ? 2 * T - 2 : 0);
+    const size_t chan_off = (static_cast<size_t>(c) << LOGN) / 2 * UPE + lane_off;
 #endif
 
     // The window touches at most FN + 1 chunks.  Resolve each to a pointer once: ring history, new
     // input, or the zero page for chunks that do not exist yet / channels past the end.
     const int q0 = t0 >> LOGN;  // floor: chunk of the window start, < 0 = history
-    const float* cb[FN + 1];
+    const U* cb[FN + 1];
 #pragma unroll
     for (int i = 0; i < FN + 1; ++i) {
         const int q = q0 + i;
-        const float* base = a.zeros + 2 * tid + (odd ? 2 * T - 2 : 0);
+        const U* base = static_cast<const U*>(a.zeros) + lane_off;
         if (chan_ok && q < a.n_steps) {
             if (q < 0) {
                 int slot = a.ring_pos + 1 + q;
                 slot += (slot < 0) ? a.ring_slots : 0;
                 slot = slot < 0 ? 0 : slot;  // (older than the history: never dereferenced with data that matters)
-                base = a.ring + static_cast<size_t>(slot) * plane + chan_off;
+                base = static_cast<const U*>(a.ring) + static_cast<size_t>(slot) * plane + chan_off;
             } else {
-                base = a.in + static_cast<size_t>(q) * plane + chan_off;
+                base = static_cast<const U*>(a.in) + static_cast<size_t>(q) * plane + chan_off;
             }
         }
         cb[i] = base;
     }
 
     float xr[P], xi[P];
-    switch ((t0 & (N - 1)) >> (LOGN - 2)) {  // window phase within its first chunk, in quarter chunks
-        case 0: load_window<PL, FN, 0>(cb, xr, xi, odd); break;
-        case 1: load_window<PL, FN, 1>(cb, xr, xi, odd); break;
-        case 2: load_window<PL, FN, 2>(cb, xr, xi, odd); break;
-        default: load_window<PL, FN, 3>(cb, xr, xi, odd); break;
+    if constexpr (S16) {
+        switch ((t0 & (N - 1)) >> (LOGN - 2)) {  // window phase within its first chunk, in quarter chunks
+            case 0: load_window_s16<PL, FN, 0>(cb, xr, xi, odd); break;
+            case 1: load_window_s16<PL, FN, 1>(cb, xr, xi, odd); break;
+            case 2: load_window_s16<PL, FN, 2>(cb, xr, xi, odd); break;
+            default: load_window_s16<PL, FN, 3>(cb, xr, xi, odd); break;
+        }
+    } else {
+        switch ((t0 & (N - 1)) >> (LOGN - 2)) {
+            case 0: load_window<PL, FN, 0>(cb, xr, xi, odd); break;
+            case 1: load_window<PL, FN, 1>(cb, xr, xi, odd); break;
+            case 2: load_window<PL, FN, 2>(cb, xr, xi, odd); break;
+            default: load_window<PL, FN, 3>(cb, xr, xi, odd); break;
+        }
     }
 
     int ja, jb;
@@ -732,19 +823,28 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(con
     const int m_lo = a.j0 / (2 * T), m_hi = (a.j0 + keep) / (2 * T);
     const int s = o - a.j0;
     const int k0 = s >> LOGN;  // floor
-    float* ob[FN + 1];
+    U* ob[FN + 1];
 #pragma unroll
     for (int i = 0; i < FN + 1; ++i) {
         int k = k0 + i;
         k = k < 0 ? 0 : (k < a.n_steps ? k : a.n_steps - 1);  // clamped ones are never stored to
-        ob[i] = a.out + static_cast<size_t>(k) * plane + chan_off;
+        ob[i] = static_cast<U*>(a.out) + static_cast<size_t>(k) * plane + chan_off;
     }
     if (chan_ok) {
-        switch ((s & (N - 1)) >> (LOGN - 2)) {
-            case 0: store_kept<PL, FN, 0>(ob, xr, xi, m_lo, m_hi, odd); break;
-            case 1: store_kept<PL, FN, 1>(ob, xr, xi, m_lo, m_hi, odd); break;
-            case 2: store_kept<PL, FN, 2>(ob, xr, xi, m_lo, m_hi, odd); break;
-            default: store_kept<PL, FN, 3>(ob, xr, xi, m_lo, m_hi, odd); break;
+        if constexpr (S16) {
+            switch ((s & (N - 1)) >> (LOGN - 2)) {
+                case 0: store_kept_s16<PL, FN, 0>(ob, xr, xi, m_lo, m_hi, odd); break;
+                case 1: store_kept_s16<PL, FN, 1>(ob, xr, xi, m_lo, m_hi, odd); break;
+                case 2: store_kept_s16<PL, FN, 2>(ob, xr, xi, m_lo, m_hi, odd); break;
+                default: store_kept_s16<PL, FN, 3>(ob, xr, xi, m_lo, m_hi, odd); break;
+            }
+        } else {
+            switch ((s & (N - 1)) >> (LOGN - 2)) {
+                case 0: store_kept<PL, FN, 0>(ob, xr, xi, m_lo, m_hi, odd); break;
+                case 1: store_kept<PL, FN, 1>(ob, xr, xi, m_lo, m_hi, odd); break;
+                case 2: store_kept<PL, FN, 2>(ob, xr, xi, m_lo, m_hi, odd); break;
+                default: store_kept<PL, FN, 3>(ob, xr, xi, m_lo, m_hi, odd); break;
+            }
         }
     }
 }

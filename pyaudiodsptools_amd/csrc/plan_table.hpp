@@ -1,0 +1,63 @@
+// plan_table.hpp - the kernel plan registry shared by the per-format translation units and the C ABI.
+// One PlanInfo = one instantiation of adsp::fftconv_kernel (transform size, F/N ratio, sample format).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fftconv_kernel.hpp"
+
+namespace adsp {
+
+struct PlanInfo {
+    int M, FN, P, T, CPB, NP, XL;  // FN = fft_size / chunk_size; XL = cross-lane pairing plan
+    int rad[4];
+    int tw_total;
+    int lds_bytes;
+    hipError_t (*launch)(const KernelArgs&, int grid, hipStream_t);
+    hipError_t (*prepare)();
+};
+
+template <class PL, int CPB, int FN, bool S16>
+hipError_t launch_impl(const KernelArgs& a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((fftconv_kernel<PL, CPB, FN, S16>), dim3(grid), dim3(PL::T * CPB), PL::M * CPB * sizeof(float2), s, a);
+    return hipGetLastError();
+}
+
+template <class PL, int CPB, int FN, bool S16>
+hipError_t prepare_impl() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fftconv_kernel<PL, CPB, FN, S16>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, PL::M * CPB * (int)sizeof(float2));
+}
+
+template <class PL, int CPB, int FN, bool S16>
+constexpr PlanInfo make_plan() {
+    return PlanInfo{PL::M, FN, PL::P, PL::T, CPB, PL::NP, PL::XL ? 1 : 0, {PL::fwd(0), PL::fwd(1), PL::fwd(2), PL::fwd(3)},
+                    PL::tw_total, PL::M * CPB * (int)sizeof(float2), &launch_impl<PL, CPB, FN, S16>, &prepare_impl<PL, CPB, FN, S16>};
+}
+
+// M (complex points) x F/N -> plan.  Radices forward (inverse = reversed); last forward radix is P/2
+// (in-register pairing) or P (XL, cross-lane pairing) - see fftconv_kernel.hpp.
+#define ADSP_PLAN_LIST(S16)                                                      \
+    make_plan<Plan<64, 16, 2, 8, 8, 1, 1>, 16, 2, S16>(),                        \
+    make_plan<Plan<128, 16, 2, 16, 8, 1, 1>, 8, 2, S16>(),                       \
+    make_plan<Plan<128, 16, 2, 16, 8, 1, 1>, 8, 4, S16>(),                       \
+    make_plan<Plan<256, 16, 3, 4, 8, 8, 1>, 4, 2, S16>(),                        \
+    make_plan<Plan<256, 16, 3, 4, 8, 8, 1>, 4, 4, S16>(),                        \
+    make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 2, 2, S16>(),                       \
+    make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 2, 4, S16>(),                       \
+    make_plan<Plan<1024, 16, 3, 16, 8, 8, 1>, 1, 2, S16>(),                      \
+    make_plan<Plan<1024, 16, 3, 16, 8, 8, 1>, 1, 4, S16>(),                      \
+    make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 2, S16>(),                     \
+    make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 4, S16>(),                     \
+    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 2, S16>(),              \
+    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 4, S16>(),              \
+    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1, 2, S16>(),                    \
+    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1, 4, S16>(),                    \
+    make_plan<Plan<16384, 32, 4, 32, 2, 16, 16>, 1, 4, S16>()
+
+// tables live in plans_f32.hip / plans_s16.hip (internal linkage there: host-only data, the device pass only
+// needs to see the instantiations)
+const PlanInfo* plans_f32(int* count);
+const PlanInfo* plans_s16(int* count);
+const PlanInfo* variants_f32(int* count);  // A/B alternatives, ADSP_PLAN_VARIANT=<n>
+
+}  // namespace adsp

@@ -139,9 +139,14 @@ def overlap_save_geometry(fir: FirStream, fft_mult: int = 0) -> Geometry:
     return Geometry(f, hist, lookback, out_offset, shift, vmax)
 
 
-def engine_spectrum(fir: FirStream, geo: Geometry) -> np.ndarray:
-    """rfft of the (shift-delayed) kernel at F points, float64 -> complex64, as interleaved float32."""
+PCM16_GAIN = 32767.0 / 32768.0  # int16 -> float (/32768, Utility.py:237) and float -> int16 (*32767, Utility.py:306)
+
+
+def engine_spectrum(fir: FirStream, geo: Geometry, gain: float = 1.0) -> np.ndarray:
+    """rfft of the (shift-delayed) kernel at F points, float64 -> complex64, as interleaved float32.
+
+    `gain` scales the kernel; int16 engines fold the reference's two PCM conversions into it (PCM16_GAIN)."""
     padded = np.zeros(geo.fft_size)
-    padded[geo.shift: geo.shift + len(fir.taps)] = fir.taps
+    padded[geo.shift: geo.shift + len(fir.taps)] = fir.taps * gain
     spec = np.fft.rfft(padded).astype(np.complex64)
     return np.ascontiguousarray(spec).view(np.float32)

@@ -61,7 +61,8 @@ class ShardedFirBank:
     rank 0 designs the filter; every rank receives the identical spectrum by broadcast and uploads
     it to its own engine (bit-identical spectra across ranks by construction)."""
 
-    def __init__(self, fir, total_channels, device=0, ring_slots=0, engine_factory=None, fft_mult=0):
+    def __init__(self, fir, total_channels, device=0, ring_slots=0, engine_factory=None, fft_mult=0,
+                 sample_format="f32"):
         from .design import engine_spectrum, overlap_save_geometry
         rank, _, world = env_world()
         try:
@@ -75,7 +76,9 @@ class ShardedFirBank:
         self.total_channels = int(total_channels)
         geo = overlap_save_geometry(fir, fft_mult)
         n_floats = 2 * (geo.fft_size // 2 + 1)
-        spec = engine_spectrum(fir, geo) if rank == 0 else np.zeros(n_floats, np.float32)
+        from .design import PCM16_GAIN
+        gain = PCM16_GAIN if sample_format == "s16" else 1.0
+        spec = engine_spectrum(fir, geo, gain) if rank == 0 else np.zeros(n_floats, np.float32)
         bdev = None
         try:
             import torch
@@ -89,7 +92,8 @@ class ShardedFirBank:
             from .engine import FirEngine
             engine_factory = FirEngine
         self.engine = engine_factory(fir, channels=self.hi - self.lo, device=device, ring_slots=ring_slots,
-                                     **({'fft_mult': fft_mult} if fft_mult else {}))
+                                     **({'fft_mult': fft_mult} if fft_mult else {}),
+                                     **({'sample_format': sample_format} if sample_format != "f32" else {}))
         if bdev is not None:
             self.engine.upload_spectrum_device(self.spectrum_tensor, n_floats // 2)
         else:

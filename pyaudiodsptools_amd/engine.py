@@ -9,7 +9,9 @@ import ctypes
 import numpy as np
 
 from . import _capi
-from .design import FirStream, engine_spectrum, overlap_save_geometry
+from .design import PCM16_GAIN, FirStream, engine_spectrum, overlap_save_geometry
+
+_FORMATS = {"f32": (_capi.ADSP_FORMAT_F32, np.float32), "s16": (_capi.ADSP_FORMAT_S16, np.int16)}
 
 
 def _ptr(x):
@@ -26,17 +28,23 @@ def _ptr(x):
 
 
 class FirEngine:
-    def __init__(self, fir: FirStream, channels=1, device=0, ring_slots=0, fft_mult=0):
+    def __init__(self, fir: FirStream, channels=1, device=0, ring_slots=0, fft_mult=0, sample_format="f32"):
         self._lib = _capi.load()
         self._h = ctypes.c_void_p(None)
         self.fir = fir
         self.fft_mult = int(fft_mult)
+        if sample_format not in _FORMATS:
+            raise ValueError("sample_format must be 'f32' or 's16'")
+        self.sample_format = sample_format
+        self._fmt_code, self.dtype = _FORMATS[sample_format]
+        # int16 engines: (float)x in, (int16)trunc(y) out; the reference's /32768 and *32767 live in the spectrum
+        self.gain = PCM16_GAIN if sample_format == "s16" else 1.0
         self.geometry = geo = overlap_save_geometry(fir, self.fft_mult)
         self.chunk_size = int(fir.chunk_size)
         self.channels = int(channels)
         self.device = int(device)
         cfg = _capi.AdspConfig(self.device, self.chunk_size, self.channels, geo.fft_size, geo.history_chunks,
-                               geo.lookback, geo.out_offset, int(ring_slots))
+                               geo.lookback, geo.out_offset, int(ring_slots), self._fmt_code)
         _capi.check(self._lib.adsp_create(ctypes.byref(cfg), ctypes.byref(self._h)))
         self.ring_slots = int(ring_slots) if ring_slots else max(2 * geo.history_chunks, geo.history_chunks + 1)
         self.plan = _capi.plan_describe(self.chunk_size, geo.fft_size)
@@ -63,7 +71,7 @@ class FirEngine:
         if geo != self.geometry:
             raise ValueError("new filter needs a different transform geometry; create a new engine")
         self.fir = fir
-        self.spectrum = engine_spectrum(fir, geo)
+        self.spectrum = engine_spectrum(fir, geo, self.gain)
         self.upload_spectrum(self.spectrum)
 
     def upload_spectrum(self, spectrum_f32):
@@ -82,20 +90,22 @@ class FirEngine:
         _capi.check(self._lib.adsp_reset(self._h))
 
     def get_state(self):
-        out = np.empty((self.geometry.history_chunks, self.channels, self.chunk_size), np.float32)
+        out = np.empty((self.geometry.history_chunks, self.channels, self.chunk_size), self.dtype)
         _capi.check(self._lib.adsp_get_state(self._h, _ptr(out)))
         return out
 
     def set_state(self, history):
-        h = np.ascontiguousarray(history, dtype=np.float32)
+        h = np.ascontiguousarray(history, dtype=self.dtype)
         if h.shape != (self.geometry.history_chunks, self.channels, self.chunk_size):
             raise ValueError(f"state must have shape {(self.geometry.history_chunks, self.channels, self.chunk_size)}")
         _capi.check(self._lib.adsp_set_state(self._h, _ptr(h)))
 
     # -- apply --------------------------------------------------------------------------------
     def apply_host(self, x):
-        """x: float32 host array [steps, C, N] (or [C, N]) -> same shape, fresh array."""
-        x = np.ascontiguousarray(x, dtype=np.float32)
+        """x: host array [steps, C, N] (or [C, N]) of the engine's sample type -> same shape, fresh array."""
+        if self.sample_format == "s16" and np.asarray(x).dtype != np.int16:
+            raise TypeError("this engine filters int16 PCM; pass an int16 array")
+        x = np.ascontiguousarray(x, dtype=self.dtype)
         squeeze = x.ndim == 2
         if squeeze:
             x = x[None]

@@ -131,6 +131,18 @@ def main():
     save("kat_example1", pcm16_first8=first8_in, out_first8=np.concatenate(outs[:8]),
          out_len=np.array([len(merged)]))
 
+    # ---- F2: Example2 plumbing (stereo = two independent devices) on the reference's 16-bit stereo WAV ----
+    ref.config.initialize(44100, 4096)
+    with contextlib.redirect_stdout(io.StringIO()):
+        left, right = ref.Utility.StereoWavToNumpyFloat(os.path.join(REF, "TestFile16BitStereo.wav"))
+    cl, cr = ref.MakeChunks(left), ref.MakeChunks(right)
+    dl, dr = ref.CreateLowCutFilter(800), ref.CreateLowCutFilter(800)
+    ol = [dl.apply(c) for c in cl[:4]]
+    orr = [dr.apply(c) for c in cr[:4]]
+    pcm = np.stack([np.round(np.concatenate(cl[:4]) * 32768), np.round(np.concatenate(cr[:4]) * 32768)], axis=1).astype(np.int16)
+    save("kat_example2", pcm16_first4_stereo=pcm, out_left=np.concatenate(ol), out_right=np.concatenate(orr),
+         n_frames=np.array([len(left)]))
+
     # ---- G: edge inputs, N=512 for each device -----------------------------------------------
     n = 512
     edge_inputs = {

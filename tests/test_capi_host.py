@@ -117,7 +117,8 @@ def test_product_package_never_imports_the_oracle():
                     names = [node.module or ""]
                 assert not any(n.split(".")[0] == "oracle" for n in names), fn
     for fn in os.listdir(os.path.join(pkg, "csrc")):
-        assert "oracle" not in open(os.path.join(pkg, "csrc", fn)).read(), fn
+        if fn.endswith((".hip", ".hpp", ".h", ".cpp")) or fn == "Makefile":
+            assert "oracle" not in open(os.path.join(pkg, "csrc", fn)).read(), fn
 
 
 def test_config_mirror():
