@@ -125,7 +125,7 @@ class Runner:
         stream_mode = mode == "stream"
         self.bank = adist.ShardedFirBank(fir, C * world, device=local_rank,
                                          ring_slots=args.ring_slots if stream_mode else 0, fft_mult=args.fft_mult,
-                                         sample_format=args.io)
+                                         sample_format=args.io, optimize_for="stream" if stream_mode else "batch")
         self.eng = eng = self.bank.engine
         assert eng.channels == C
         self.stream = torch.cuda.current_stream(dev)

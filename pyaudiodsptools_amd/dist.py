@@ -62,7 +62,7 @@ class ShardedFirBank:
     it to its own engine (bit-identical spectra across ranks by construction)."""
 
     def __init__(self, fir, total_channels, device=0, ring_slots=0, engine_factory=None, fft_mult=0,
-                 sample_format="f32"):
+                 sample_format="f32", optimize_for="stream"):
         from .design import engine_spectrum, overlap_save_geometry
         rank, _, world = env_world()
         try:
@@ -74,7 +74,7 @@ class ShardedFirBank:
         self.rank, self.world = rank, world
         self.lo, self.hi = shard_range(total_channels, world, rank)
         self.total_channels = int(total_channels)
-        geo = overlap_save_geometry(fir, fft_mult)
+        geo = overlap_save_geometry(fir, fft_mult, optimize_for)
         n_floats = 2 * (geo.fft_size // 2 + 1)
         from .design import PCM16_GAIN
         gain = PCM16_GAIN if sample_format == "s16" else 1.0
@@ -93,7 +93,8 @@ class ShardedFirBank:
             engine_factory = FirEngine
         self.engine = engine_factory(fir, channels=self.hi - self.lo, device=device, ring_slots=ring_slots,
                                      **({'fft_mult': fft_mult} if fft_mult else {}),
-                                     **({'sample_format': sample_format} if sample_format != "f32" else {}))
+                                     **({'sample_format': sample_format} if sample_format != "f32" else {}),
+                                     **({'optimize_for': optimize_for} if optimize_for != "stream" else {}))
         if bdev is not None:
             self.engine.upload_spectrum_device(self.spectrum_tensor, n_floats // 2)
         else:

@@ -28,7 +28,8 @@ def _ptr(x):
 
 
 class FirEngine:
-    def __init__(self, fir: FirStream, channels=1, device=0, ring_slots=0, fft_mult=0, sample_format="f32"):
+    def __init__(self, fir: FirStream, channels=1, device=0, ring_slots=0, fft_mult=0, sample_format="f32",
+                 optimize_for="stream"):
         self._lib = _capi.load()
         self._h = ctypes.c_void_p(None)
         self.fir = fir
@@ -39,7 +40,8 @@ class FirEngine:
         self._fmt_code, self.dtype = _FORMATS[sample_format]
         # int16 engines: (float)x in, (int16)trunc(y) out; the reference's /32768 and *32767 live in the spectrum
         self.gain = PCM16_GAIN if sample_format == "s16" else 1.0
-        self.geometry = geo = overlap_save_geometry(fir, self.fft_mult)
+        self.optimize_for = optimize_for
+        self.geometry = geo = overlap_save_geometry(fir, self.fft_mult, optimize_for)
         self.chunk_size = int(fir.chunk_size)
         self.channels = int(channels)
         self.device = int(device)
@@ -67,7 +69,7 @@ class FirEngine:
     # -- filter -------------------------------------------------------------------------------
     def set_fir(self, fir: FirStream):
         """Change the filter without touching the history (same geometry required)."""
-        geo = overlap_save_geometry(fir, self.fft_mult)
+        geo = overlap_save_geometry(fir, self.fft_mult, self.optimize_for)
         if geo != self.geometry:
             raise ValueError("new filter needs a different transform geometry; create a new engine")
         self.fir = fir

@@ -120,7 +120,7 @@ class WavBank:
         return np.ascontiguousarray(self.pcm.reshape(self.channels, self.steps, self.chunk_size).transpose(1, 0, 2))
 
     def process(self, fir: FirStream, device=0):
-        eng = FirEngine(fir, channels=self.channels, device=device, sample_format="s16")
+        eng = FirEngine(fir, channels=self.channels, device=device, sample_format="s16", optimize_for="batch")
         out = eng.apply_host(self.batch())  # [steps, C, N] int16
         eng.close()
         flat = out.transpose(1, 0, 2).reshape(self.channels, -1)

@@ -185,6 +185,22 @@ def test_multistep_equals_streaming_and_state_roundtrip(adsp, n):
     assert_parity(b.apply_batch(x), stream, what="V=N multi-step")
 
 
+@pytest.mark.parametrize("n", [512, 4096])
+def test_batch_optimised_geometry_eq(adsp, n):
+    """optimize_for="batch" runs the EQ on a 4N transform (3N kept): same stream as the 2N engine and the oracle."""
+    from pyaudiodsptools_amd import FirEngine, FirStream, design
+    o = orc()
+    fs, channels, steps = 44100, 3, 7
+    taps = design.eq3_composite(100, 2, 700, -4, 8000, 5, fs, n)
+    fir = FirStream(taps, n)
+    eng = FirEngine(fir, channels=channels, optimize_for="batch")
+    assert eng.geometry.fft_size == 4 * n and eng.block_outputs == 3 * n
+    x = np.random.default_rng(n).uniform(-1, 1, (steps, channels, n)).astype(np.float32)
+    y = np.concatenate([eng.apply_host(x[:4]), eng.apply_host(x[4:5]), eng.apply_host(x[5:])])  # multi-step, single, multi
+    for c in range(channels):
+        assert_parity(y[:, c].reshape(-1), o.direct_stream_convolution(taps, x[:, c].reshape(-1), n), what=f"ch {c}")
+
+
 def test_device_pointer_and_ring_paths(adsp):
     """adsp_apply_device on torch tensors and the zero-copy ring path give the same stream."""
     import torch

@@ -7,9 +7,9 @@ pat = sys.argv[1] if len(sys.argv) > 1 else "Li4096ELi32"
 extra = sys.argv[2:]
 tmp = tempfile.mkdtemp(prefix="isa_")
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-save-temps",
-       "-o", os.path.join(tmp, "x.so"), os.path.join(ROOT, "pyaudiodsptools_amd/csrc/adsp_capi.hip")] + extra
+       "-o", os.path.join(tmp, "x.so"), os.path.join(ROOT, "pyaudiodsptools_amd/csrc/plans_f32.hip")] + extra
 subprocess.run(cmd, cwd=tmp, check=True, stderr=subprocess.DEVNULL)
-s = open(os.path.join(tmp, "adsp_capi-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+s = open(os.path.join(tmp, "plans_f32-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
 for f in re.split(r'\n\s*\.globl\s+', s):
     name = f.split('\n', 1)[0].strip()
     if pat not in name or 'fftconv' not in name:
