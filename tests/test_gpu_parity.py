@@ -333,3 +333,42 @@ def test_config3_full_size_eq_stereo_pairs(adsp):
     xh, yh = x.cpu().numpy(), y.cpu().numpy()
     for c in (0, 1234, channels - 1):
         assert_parity(yh[:, c].reshape(-1), o.direct_stream_convolution(taps, xh[:, c].reshape(-1), n), what=f"config3 ch {c}")
+
+
+def test_raw_c_abi_error_paths(adsp):
+    """Status codes + adsp_last_error() for misuse, straight through ctypes (no Python wrapper logic)."""
+    import ctypes
+    from pyaudiodsptools_amd import _capi
+    lib = _capi.load()
+
+    def create(**kw):
+        base = dict(device_id=0, chunk_size=512, n_channels=2, fft_size=1024, history_chunks=2, lookback=640,
+                    out_offset=256, ring_slots=0, sample_format=0)
+        base.update(kw)
+        cfg = _capi.AdspConfig(*[base[f[0]] for f in _capi.AdspConfig._fields_])
+        h = ctypes.c_void_p()
+        return lib.adsp_create(ctypes.byref(cfg), ctypes.byref(h)), h
+
+    for bad in (dict(chunk_size=500), dict(fft_size=512), dict(n_channels=0), dict(history_chunks=0), dict(lookback=641),
+                dict(lookback=4096), dict(out_offset=1000), dict(out_offset=768, lookback=640), dict(ring_slots=2),
+                dict(device_id=99), dict(sample_format=7)):
+        rc, h = create(**bad)
+        assert rc == _capi.ADSP_ERR_ARG and not h.value, bad
+        assert len(lib.adsp_last_error()) > 10
+    rc, h = create()
+    assert rc == 0 and h.value
+    buf = (ctypes.c_float * (2 * 2 * 512))()  # room for two steps of [2 channels][512]
+    assert lib.adsp_apply_host(h, buf, buf, 1) == _capi.ADSP_ERR_STATE  # no spectrum yet
+    assert b"adsp_set_spectrum" in lib.adsp_last_error()
+    spec = (ctypes.c_float * (2 * 513))()
+    assert lib.adsp_set_spectrum(h, spec, 512) == _capi.ADSP_ERR_ARG  # wrong number of bins
+    assert lib.adsp_set_spectrum(h, spec, 513) == 0
+    assert lib.adsp_apply_host(h, buf, buf, 0) == _capi.ADSP_ERR_ARG
+    assert lib.adsp_apply_host(h, None, buf, 1) == _capi.ADSP_ERR_ARG
+    assert lib.adsp_set_block_outputs(h, 4096) == _capi.ADSP_ERR_ARG
+    assert lib.adsp_apply_host(h, buf, buf, 1) == 0  # zero spectrum -> zero output, engine still healthy
+    assert not any(buf)
+    ms, n = ctypes.c_double(), ctypes.c_int()
+    assert lib.adsp_enable_kernel_timing(h, 1) == 0 and lib.adsp_apply_host(h, buf, buf, 2) == 0
+    assert lib.adsp_kernel_time(h, ctypes.byref(ms), ctypes.byref(n)) == 0 and n.value == 1 and ms.value > 0
+    assert lib.adsp_destroy(h) == 0 and lib.adsp_destroy(None) == 0
