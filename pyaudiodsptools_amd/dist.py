@@ -95,7 +95,7 @@ class ShardedFirBank:
                                      **({'fft_mult': fft_mult} if fft_mult else {}),
                                      **({'sample_format': sample_format} if sample_format != "f32" else {}),
                                      **({'optimize_for': optimize_for} if optimize_for != "stream" else {}))
-        if bdev is not None:
-            self.engine.upload_spectrum_device(self.spectrum_tensor, n_floats // 2)
-        else:
-            self.engine.upload_spectrum(self.spectrum)
+        # `self.spectrum` is the host copy taken after the collective completed on torch's stream; uploading from it
+        # avoids reading the device tensor from the library's own stream (adsp_set_spectrum_device exists for callers
+        # that manage that ordering themselves).
+        self.engine.upload_spectrum(self.spectrum)
