@@ -218,6 +218,8 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
     a.n_steps = n_steps;
     a.V = n_steps == 1 ? c.chunk_size : e->block_outputs;
     const long long total = (long long)n_steps * c.chunk_size;
+    if (total + 8LL * c.fft_size >= 0x7fffffffLL)  // the kernel indexes a channel's time axis with 32-bit ints
+        return fail(ADSP_ERR_ARG, "n_steps %d x chunk %d is too long for one call; split it", n_steps, c.chunk_size);
     a.nblk = (int)((total + a.V - 1) / a.V);
     a.lookback = c.lookback;
     a.j0 = c.out_offset;
