@@ -73,12 +73,14 @@ typedef struct adsp_engine adsp_engine; /* opaque */
  */
 typedef struct adsp_config {
     int device_id;       /* HIP device ordinal */
-    int chunk_size;      /* N: samples per channel per step; power of two, 64..8192 */
+    int chunk_size;      /* N: samples per channel per step; any multiple of 4, >= 16 */
     int n_channels;      /* C: independent mono channels held by this engine */
-    int fft_size;        /* F: real transform length, power of two, 2N or 4N, F/2 in 64..16384 */
+    int fft_size;        /* F: real transform length, power of two in 128..32768.  N a power of two in 64..8192 with
+                            F = 2N or 4N selects the specialised kernels (chunk boundaries known at compile time);
+                            anything else runs the generic-geometry kernel */
     int history_chunks;  /* past chunks the window can reach (1..ADSP_MAX_HISTORY) */
-    int lookback;        /* see above; 0 < lookback <= history_chunks*N, multiple of 4N/.. (checked) */
-    int out_offset;      /* see above */
+    int lookback;        /* see above; 0 < lookback <= history_chunks*N; multiple of N/4 (specialised) or 4 (generic) */
+    int out_offset;      /* see above; multiple of 2*threads_per_transform (specialised) or 4* (generic) */
     int ring_slots;      /* input ring length (>= history_chunks+1); 0 = 2*history_chunks, which lets the ring
                             update of multi-step launches run on a side stream beside the kernel */
     int sample_format;   /* ADSP_FORMAT_F32 or ADSP_FORMAT_S16: type of every `in`/`out`/ring/state buffer below */
@@ -93,7 +95,7 @@ ADSP_API const char* adsp_last_error(void);
 /* Number of visible GPUs (0 and ADSP_ERR_NO_DEVICE when there is none). */
 ADSP_API int adsp_device_count(int* count);
 
-/* 0 if a kernel plan exists for this (chunk_size, fft_size), ADSP_ERR_ARG otherwise.  Needs no GPU. */
+/* 0 if a kernel exists for this (chunk_size, fft_size), ADSP_ERR_ARG otherwise.  Needs no GPU. */
 ADSP_API int adsp_plan_supported(int chunk_size, int fft_size);
 
 /* Describe the plan chosen for (chunk_size, fft_size): complex points M, points per thread,

@@ -54,6 +54,14 @@ const PlanInfo* find_plan(int M, int FN, int fmt) {
     return nullptr;
 }
 
+const PlanInfo* find_plan_any_fn(int M, int fmt) {
+    int n = 0;
+    const PlanInfo* tab = fmt == ADSP_FORMAT_S16 ? adsp::plans_s16(&n) : adsp::plans_f32(&n);
+    for (int i = 0; i < n; ++i)
+        if (tab[i].M == M) return &tab[i];
+    return nullptr;
+}
+
 bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 int ilog2(int v) {
     int l = 0;
@@ -61,13 +69,17 @@ int ilog2(int v) {
     return l;
 }
 
-int check_geometry(int N, int F, int fmt, const PlanInfo** out) {
-    if (!is_pow2(N) || N < 64 || N > 8192) return fail(ADSP_ERR_ARG, "chunk_size %d: need a power of two in 64..8192", N);
-    if (F != 2 * N && F != 4 * N) return fail(ADSP_ERR_ARG, "fft_size %d: need 2*chunk_size or 4*chunk_size", F);
+// Two kinds of geometry: "specialised" (chunk a power of two in 64..8192, F = 2N or 4N: chunk boundaries are
+// compile-time constants in the kernel) and "generic" (any chunk divisible by 4, any supported power-of-two F).
+int check_geometry(int N, int F, int fmt, const PlanInfo** out, bool* generic) {
     if (fmt != ADSP_FORMAT_F32 && fmt != ADSP_FORMAT_S16) return fail(ADSP_ERR_ARG, "sample_format %d: need ADSP_FORMAT_F32 or ADSP_FORMAT_S16", fmt);
-    const PlanInfo* p = find_plan(F / 2, F / N, fmt);
+    if (N < 16 || N % 4) return fail(ADSP_ERR_ARG, "chunk_size %d: need a multiple of 4, >= 16", N);
+    if (!is_pow2(F) || F < 128 || F > 32768) return fail(ADSP_ERR_ARG, "fft_size %d: need a power of two in 128..32768", F);
+    const bool special = is_pow2(N) && N >= 64 && N <= 8192 && (F == 2 * N || F == 4 * N);
+    const PlanInfo* p = special ? find_plan(F / 2, F / N, fmt) : find_plan_any_fn(F / 2, fmt);
     if (!p) return fail(ADSP_ERR_ARG, "no kernel plan for %d complex points", F / 2);
     if (out) *out = p;
+    if (generic) *generic = !special;
     return ADSP_OK;
 }
 
@@ -132,6 +144,7 @@ struct adsp_engine {
     adsp_config cfg;
     const PlanInfo* plan;
     int M, logN, block_outputs;
+    bool generic;  // generic-geometry kernel (chunk not a power of two / F not 2N or 4N)
     char* ring;    // [ring_slots][C][N] samples of cfg.sample_format
     int ring_pos;  // slot of the most recent chunk
     float4* tw;
@@ -216,7 +229,10 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
     a.ring_slots = c.ring_slots;
     a.C = c.n_channels;
     a.n_steps = n_steps;
-    a.V = n_steps == 1 ? c.chunk_size : e->block_outputs;
+    a.V = (n_steps == 1 && !e->generic) ? c.chunk_size : e->block_outputs;
+    a.N = c.chunk_size;
+    a.nh = c.history_chunks;
+    a.inv_n = 1.0f / (float)c.chunk_size;
     const long long total = (long long)n_steps * c.chunk_size;
     if (total + 8LL * c.fft_size >= 0x7fffffffLL)  // the kernel indexes a channel's time axis with 32-bit ints
         return fail(ADSP_ERR_ARG, "n_steps %d x chunk %d is too long for one call; split it", n_steps, c.chunk_size);
@@ -237,7 +253,7 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
         }
         HIP_TRY(hipEventRecord(ev.first, stream));
     }
-    HIP_TRY(pl.launch(a, (int)grid, stream));
+    HIP_TRY(e->generic ? pl.launch_generic(a, (int)grid, stream) : pl.launch(a, (int)grid, stream));
     if (e->timing) {
         HIP_TRY(hipEventRecord(ev.second, stream));
         e->timed.push_back(ev);
@@ -267,12 +283,12 @@ int adsp_device_count(int* count) {
     return ADSP_OK;
 }
 
-int adsp_plan_supported(int chunk_size, int fft_size) { return check_geometry(chunk_size, fft_size, ADSP_FORMAT_F32, nullptr); }
+int adsp_plan_supported(int chunk_size, int fft_size) { return check_geometry(chunk_size, fft_size, ADSP_FORMAT_F32, nullptr, nullptr); }
 
 int adsp_plan_describe(int chunk_size, int fft_size, int* complex_points, int* points_per_thread,
                        int* threads_per_transform, int* channels_per_workgroup, int* lds_bytes) {
     const PlanInfo* p = nullptr;
-    int rc = check_geometry(chunk_size, fft_size, ADSP_FORMAT_F32, &p);
+    int rc = check_geometry(chunk_size, fft_size, ADSP_FORMAT_F32, &p, nullptr);
     if (rc) return rc;
     if (complex_points) *complex_points = p->M;
     if (points_per_thread) *points_per_thread = p->P;
@@ -286,16 +302,26 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     if (!cfg || !out_engine) return fail(ADSP_ERR_ARG, "NULL argument");
     *out_engine = nullptr;
     const PlanInfo* pl = nullptr;
-    int rc = check_geometry(cfg->chunk_size, cfg->fft_size, cfg->sample_format, &pl);
+    bool generic = false;
+    int rc = check_geometry(cfg->chunk_size, cfg->fft_size, cfg->sample_format, &pl, &generic);
     if (rc) return rc;
     const int N = cfg->chunk_size, F = cfg->fft_size, T2 = 2 * pl->T;
     if (cfg->n_channels <= 0) return fail(ADSP_ERR_ARG, "n_channels must be positive");
     if (cfg->history_chunks < 1 || cfg->history_chunks > ADSP_MAX_HISTORY)
         return fail(ADSP_ERR_ARG, "history_chunks %d out of range 1..%d", cfg->history_chunks, ADSP_MAX_HISTORY);
-    if (cfg->lookback <= 0 || cfg->lookback > cfg->history_chunks * N || cfg->lookback % T2)
-        return fail(ADSP_ERR_ARG, "lookback %d must be in (0, history_chunks*N] and a multiple of %d", cfg->lookback, T2);
-    if (cfg->out_offset < 0 || cfg->out_offset % T2 || cfg->out_offset + N > F)
-        return fail(ADSP_ERR_ARG, "out_offset %d must be a multiple of %d with out_offset + N <= F", cfg->out_offset, T2);
+    if (!generic) {
+        if (cfg->lookback <= 0 || cfg->lookback > cfg->history_chunks * N || cfg->lookback % T2)
+            return fail(ADSP_ERR_ARG, "lookback %d must be in (0, history_chunks*N] and a multiple of %d", cfg->lookback, T2);
+        if (cfg->out_offset < 0 || cfg->out_offset % T2 || cfg->out_offset + N > F)
+            return fail(ADSP_ERR_ARG, "out_offset %d must be a multiple of %d with out_offset + N <= F", cfg->out_offset, T2);
+    } else {
+        // generic geometry: 16-byte accesses need everything on the time axis to be a multiple of 4 samples; kept
+        // ranges are whole register segments (2T samples)
+        if (cfg->lookback <= 0 || cfg->lookback > cfg->history_chunks * N || cfg->lookback % 4)
+            return fail(ADSP_ERR_ARG, "lookback %d must be in (0, history_chunks*N] and a multiple of 4", cfg->lookback);
+        if (cfg->out_offset < 0 || cfg->out_offset % (2 * T2) || cfg->out_offset + 2 * T2 > F)
+            return fail(ADSP_ERR_ARG, "out_offset %d must be a multiple of %d with out_offset + %d <= F", cfg->out_offset, 2 * T2, 2 * T2);
+    }
     // kept sample i sits at input-time o - lookback + out_offset + i; it may not lie beyond the newest chunk
     if (cfg->out_offset > cfg->lookback)
         return fail(ADSP_ERR_ARG, "out_offset %d > lookback %d: kept samples would need future input", cfg->out_offset, cfg->lookback);
@@ -314,7 +340,10 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     e->plan = pl;
     e->M = F / 2;
     e->logN = ilog2(N);
-    e->block_outputs = N;
+    e->generic = generic;
+    // samples kept per transform: one chunk for the specialised kernels' single-step launches; the generic kernel
+    // always tiles the time axis with block_outputs (default: as many whole segments as the transform offers)
+    e->block_outputs = generic ? (F - cfg->out_offset) / (2 * T2) * (2 * T2) : N;
     e->ring = nullptr;
     e->ring_pos = slots - 1;
     e->tw = nullptr;
@@ -335,7 +364,7 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     };
     if ((rc = set_device(e))) return bail(rc);
     hipError_t err;
-    if ((err = pl->prepare()) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(err)));
+    if ((err = (generic ? pl->prepare_generic() : pl->prepare())) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(err)));
     const size_t ring_bytes = (size_t)slots * e->plane_bytes();
     if ((err = hipMalloc(&e->ring, ring_bytes)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc ring (%zu bytes): %s", ring_bytes, hipGetErrorString(err)));
     if ((err = hipMemset(e->ring, 0, ring_bytes)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMemset: %s", hipGetErrorString(err)));
@@ -404,7 +433,7 @@ int adsp_set_spectrum_device(adsp_engine* e, const float* d_spectrum, int n_bins
 
 int adsp_set_block_outputs(adsp_engine* e, int v) {
     if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
-    const int T2 = 2 * e->plan->T;
+    const int T2 = (e->generic ? 4 : 2) * e->plan->T;  // the generic kernel keeps whole register pairs
     if (v <= 0 || v % T2 || e->cfg.out_offset + v > e->cfg.fft_size)
         return fail(ADSP_ERR_ARG, "block_outputs %d must be a positive multiple of %d with out_offset + block_outputs <= fft_size", v, T2);
     // the window must not need input newer than what a block's last output may see:

@@ -72,6 +72,9 @@ struct KernelArgs {
     int lookback;          // window start = block output start - lookback
     int j0;                // circular index of the first kept sample
     int ncg;               // channel groups = ceil(C / channels-per-workgroup)
+    int N;                 // chunk size (generic-geometry kernel only; the specialised kernels know it at compile time)
+    int nh;                // history chunks (generic-geometry kernel only)
+    float inv_n;           // 1 / N
 };
 
 // ------------------------------------------------------------------------------------------
@@ -715,6 +718,34 @@ __device__ __forceinline__ void store_kept_s16(unsigned* const (&ob)[FN + 1], co
 }
 
 // ------------------------------------------------------------------------------------------
+// the transform core shared by both kernels: forward FFT -> spectrum stage -> inverse FFT, in registers + LDS
+// ------------------------------------------------------------------------------------------
+template <class PL>
+__device__ __forceinline__ void transform_block(float (&xr)[PL::P], float (&xi)[PL::P], float2* lds, const KernelArgs& a,
+                                                int tid) {
+    constexpr int T = PL::T;
+    int ja, jb;
+    if constexpr (PL::XL) {
+        // lanes 0-31 of wave w: butterflies 32w + l; lanes 32-63: their partners T - (32w + l)
+        const int lo = 32 * (tid >> 6) + (tid & 31);
+        ja = (tid & 32) ? (tid == 32 ? T / 2 : T - lo) : lo;
+        jb = 0;
+    } else {
+        ja = tid;
+        jb = (tid == 0) ? T : 2 * T - tid;
+    }
+
+    run_passes<PL, false, 0>(xr, xi, lds, a.tw, tid, ja, jb);
+#if !(ADSP_ABLATE & 256)
+    if constexpr (PL::XL)
+        spectrum_stage_xl<PL>(xr, xi, a.pair, a.pair0, tid);
+    else
+        spectrum_stage<PL>(xr, xi, a.pair, a.pair0, tid);
+#endif
+    run_passes<PL, true, 0>(xi, xr, lds, a.tw, tid, ja, jb);  // inverse = forward on swapped parts
+}
+
+// ------------------------------------------------------------------------------------------
 // the kernel: one workgroup = CPB channels x one time block
 // ------------------------------------------------------------------------------------------
 template <class PL, int CPB, int FN, bool S16 = false>
@@ -796,25 +827,7 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(con
         }
     }
 
-    int ja, jb;
-    if constexpr (PL::XL) {
-        // lanes 0-31 of wave w: butterflies 32w + l; lanes 32-63: their partners T - (32w + l)
-        const int lo = 32 * (tid >> 6) + (tid & 31);
-        ja = (tid & 32) ? (tid == 32 ? T / 2 : T - lo) : lo;
-        jb = 0;
-    } else {
-        ja = tid;
-        jb = (tid == 0) ? T : 2 * T - tid;
-    }
-
-    run_passes<PL, false, 0>(xr, xi, lds, a.tw, tid, ja, jb);
-#if !(ADSP_ABLATE & 256)
-    if constexpr (PL::XL)
-        spectrum_stage_xl<PL>(xr, xi, a.pair, a.pair0, tid);
-    else
-        spectrum_stage<PL>(xr, xi, a.pair, a.pair0, tid);
-#endif
-    run_passes<PL, true, 0>(xi, xr, lds, a.tw, tid, ja, jb);  // inverse = forward on swapped parts
+    transform_block<PL>(xr, xi, lds, a, tid);
 
     // kept samples: circular indices [j0, j0 + keep) -> registers m_lo <= m < m_hi; register m holds
     // output-time o - j0 + 2T*m.  s = o - j0 may be negative: split into chunk part and phase.
@@ -844,6 +857,125 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(con
                 case 1: store_kept<PL, FN, 1>(ob, xr, xi, m_lo, m_hi, odd); break;
                 case 2: store_kept<PL, FN, 2>(ob, xr, xi, m_lo, m_hi, odd); break;
                 default: store_kept<PL, FN, 3>(ob, xr, xi, m_lo, m_hi, odd); break;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Generic-geometry kernel: ANY chunk size divisible by 4.  Overlap-save does not need the transform
+// tied to the chunk: blocks of V kept samples tile a channel's time axis, and every 16-byte access (4 samples, never
+// straddling a chunk because N % 4 == 0 and all block geometry is a multiple of 4) finds its chunk with one
+// float reciprocal division per lane.  Same transform core, ~15 % more VALU for the address arithmetic.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void locate_chunk(int tau_biased, int N, float inv_n, int& q, int& r) {
+    q = static_cast<int>(static_cast<float>(tau_biased) * inv_n);  // may be off by one either way
+    r = tau_biased - q * N;
+    if (r < 0) {
+        --q;
+        r += N;
+    } else if (r >= N) {
+        ++q;
+        r -= N;
+    }
+}
+
+template <class PL, int CPB, bool S16 = false>
+__global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_generic_kernel(const KernelArgs a) {
+    constexpr int M = PL::M, P = PL::P, T = PL::T;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* lds = reinterpret_cast<float2*>(smem_raw);
+    const int tid = static_cast<int>(threadIdx.x) % T;
+    const int grp = static_cast<int>(threadIdx.x) / T;
+    lds += grp * M;
+
+    const int lin = static_cast<int>(blockIdx.x);
+    const int xcd = lin & 7;
+    const int idx = lin >> 3;
+    const int cgl = idx / a.nblk;
+    const int blk = idx - cgl * a.nblk;
+    const int cg = cgl * 8 + xcd;
+    if (cg >= a.ncg) return;
+    const int c = cg * CPB + grp;
+    const bool chan_ok = c < a.C;
+
+    using U = typename std::conditional<S16, unsigned, float>::type;  // storage unit: float, or a dword of two int16
+    constexpr int SPU = S16 ? 2 : 1;                                    // samples per unit
+    const int N = a.N;
+    const size_t plane = static_cast<size_t>(a.C) * N / SPU;
+    const size_t chan_units = static_cast<size_t>(c) * N / SPU;
+    const bool odd = tid & 1;
+    const int o = blk * a.V;
+    const int t0 = o - a.lookback + a.nh * N;  // window start on the biased (>= 0) time axis: history chunk -nh is chunk 0
+
+    float xr[P], xi[P];
+#pragma unroll
+    for (int u = 0; u < P / 2; ++u) {
+        // even lane: elements (tid, tid+1) of register 2u; odd lane: elements (tid-1, tid) of register 2u+1
+        const int elem = (tid - (odd ? 1 : 0)) + T * (2 * u + (odd ? 1 : 0));
+        int q, r;
+        locate_chunk(t0 + 2 * elem, N, a.inv_n, q, r);
+        q -= a.nh;
+        const U* base = static_cast<const U*>(a.zeros);
+        size_t off = r / SPU;
+        if (chan_ok && q < a.n_steps) {
+            if (q < 0) {
+                int slot = a.ring_pos + 1 + q;
+                slot += (slot < 0) ? a.ring_slots : 0;
+                base = static_cast<const U*>(a.ring) + static_cast<size_t>(slot) * plane;
+            } else {
+                base = static_cast<const U*>(a.in) + static_cast<size_t>(q) * plane;
+            }
+            off += chan_units;
+        }
+        if constexpr (S16) {
+            const uint2 v = *reinterpret_cast<const uint2*>(base + off);
+            const unsigned sx = lane_xor1_u(odd ? v.x : v.y);
+            unpack_s16(odd ? sx : v.x, xr[2 * u], xi[2 * u]);
+            unpack_s16(odd ? v.y : sx, xr[2 * u + 1], xi[2 * u + 1]);
+        } else {
+            const float4 v = *reinterpret_cast<const float4*>(base + off);
+            const float sx = lane_xor1(odd ? v.x : v.z), sy = lane_xor1(odd ? v.y : v.w);
+            xr[2 * u] = odd ? sx : v.x;
+            xi[2 * u] = odd ? sy : v.y;
+            xr[2 * u + 1] = odd ? v.z : sx;
+            xi[2 * u + 1] = odd ? v.w : sy;
+        }
+    }
+
+    transform_block<PL>(xr, xi, lds, a, tid);
+
+    const long long total_ll = static_cast<long long>(a.n_steps) * N;
+    const int total = static_cast<int>(total_ll);
+    const int m_lo = a.j0 / (2 * T), m_hi = (a.j0 + a.V) / (2 * T);
+#pragma unroll
+    for (int u = 0; u < P / 2; ++u) {
+        if (2 * u >= m_lo && 2 * u < m_hi) {  // wave-uniform: j0 and V are multiples of 4T (whole register pairs)
+            const int elem = (tid - (odd ? 1 : 0)) + T * (2 * u + (odd ? 1 : 0));
+            const int tau = o + 2 * elem - a.j0;
+            float sx, sy;
+            unsigned w0 = 0, w1 = 0, swx = 0;
+            if constexpr (S16) {
+                w0 = pack_s16(xr[2 * u], xi[2 * u]);
+                w1 = pack_s16(xr[2 * u + 1], xi[2 * u + 1]);
+                swx = lane_xor1_u(odd ? w0 : w1);
+            } else {
+                sx = lane_xor1(odd ? xr[2 * u] : xr[2 * u + 1]);
+                sy = lane_xor1(odd ? xi[2 * u] : xi[2 * u + 1]);
+            }
+            if (chan_ok && tau < total) {
+                int k, r;
+                locate_chunk(tau, N, a.inv_n, k, r);
+                U* dst = static_cast<U*>(a.out) + static_cast<size_t>(k) * plane + chan_units + r / SPU;
+                if constexpr (S16) {
+                    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                    const v2u v = odd ? v2u{swx, w1} : v2u{w0, swx};
+                    __builtin_nontemporal_store(v, reinterpret_cast<v2u*>(dst));
+                } else {
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    const v4f v = odd ? v4f{sx, sy, xr[2 * u + 1], xi[2 * u + 1]} : v4f{xr[2 * u], xi[2 * u], sx, sy};
+                    __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(dst));
+                }
             }
         }
     }

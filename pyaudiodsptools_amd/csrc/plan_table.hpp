@@ -14,6 +14,9 @@ struct PlanInfo {
     int lds_bytes;
     hipError_t (*launch)(const KernelArgs&, int grid, hipStream_t);
     hipError_t (*prepare)();
+    // the same transform behind the generic-geometry kernel (any chunk size divisible by 4, FN is ignored)
+    hipError_t (*launch_generic)(const KernelArgs&, int grid, hipStream_t);
+    hipError_t (*prepare_generic)();
 };
 
 template <class PL, int CPB, int FN, bool S16>
@@ -28,10 +31,23 @@ hipError_t prepare_impl() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, PL::M * CPB * (int)sizeof(float2));
 }
 
+template <class PL, int CPB, bool S16>
+hipError_t launch_generic_impl(const KernelArgs& a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((fftconv_generic_kernel<PL, CPB, S16>), dim3(grid), dim3(PL::T * CPB), PL::M * CPB * sizeof(float2), s, a);
+    return hipGetLastError();
+}
+
+template <class PL, int CPB, bool S16>
+hipError_t prepare_generic_impl() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fftconv_generic_kernel<PL, CPB, S16>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, PL::M * CPB * (int)sizeof(float2));
+}
+
 template <class PL, int CPB, int FN, bool S16>
 constexpr PlanInfo make_plan() {
     return PlanInfo{PL::M, FN, PL::P, PL::T, CPB, PL::NP, PL::XL ? 1 : 0, {PL::fwd(0), PL::fwd(1), PL::fwd(2), PL::fwd(3)},
-                    PL::tw_total, PL::M * CPB * (int)sizeof(float2), &launch_impl<PL, CPB, FN, S16>, &prepare_impl<PL, CPB, FN, S16>};
+                    PL::tw_total, PL::M * CPB * (int)sizeof(float2), &launch_impl<PL, CPB, FN, S16>, &prepare_impl<PL, CPB, FN, S16>,
+                    &launch_generic_impl<PL, CPB, S16>, &prepare_generic_impl<PL, CPB, S16>};
 }
 
 // M (complex points) x F/N -> plan.  Radices forward (inverse = reversed); last forward radix is P/2

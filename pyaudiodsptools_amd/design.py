@@ -120,8 +120,8 @@ def overlap_save_geometry(fir: FirStream, fft_mult: int = 0, optimize_for: str =
     picks 4N by itself when a 2N transform keeps only half of its samples (EQ: measured +15 % in multi-step launches).
     """
     n = int(fir.chunk_size)
-    if n < 64 or n & (n - 1):
-        raise ValueError(f"chunk_size {n}: this build supports powers of two in 64..8192")
+    if n < 64 or n > 8192 or n & (n - 1):
+        return _generic_geometry(fir, fft_mult, optimize_for)
     g = n // 4
     m = len(fir.taps)
     d_total = fir.delay
@@ -143,6 +143,53 @@ def overlap_save_geometry(fir: FirStream, fft_mult: int = 0, optimize_for: str =
 
 
 PCM16_GAIN = 32767.0 / 32768.0  # int16 -> float (/32768, Utility.py:237) and float -> int16 (*32767, Utility.py:306)
+
+
+def _generic_geometry(fir: FirStream, fft_mult: int, optimize_for: str) -> Geometry:
+    """Any chunk size divisible by 4: the transform is not tied to the chunk.
+
+    Blocks of V kept samples tile the time axis; V and out_offset are whole register-pair segments (4T samples), the
+    window start a multiple of 4 samples (the kernel moves 16 bytes per access), which a 0..3-tap delay of the
+    kernel (`shift`) arranges.  stream: the smallest transform that returns a whole chunk per block;
+    batch: the transform with the fewest flops per kept sample."""
+    from . import _capi
+    n, m, d_total = int(fir.chunk_size), len(fir.taps), fir.delay
+    if n < 16 or n % 4:
+        raise ValueError(f"chunk_size {n}: need a multiple of 4 (>= 16)")
+    if d_total <= 0:
+        raise ValueError("non-causal stream")
+    best = None
+    for log_f in range(7, 16):
+        f = 1 << log_f
+        if fft_mult and f != fft_mult * n:
+            continue
+        try:
+            # register PAIRS are stored together (16-byte accesses): kept ranges are multiples of 4T samples
+            t2 = 4 * _capi.plan_describe(n, f)["threads_per_transform"]
+        except _capi.AdspError:
+            continue
+        j0 = -(-(m + 2) // t2) * t2
+        v = (f - j0) // t2 * t2
+        if v < t2:
+            continue
+        shift = (d_total + j0) % 4
+        lookback = d_total + j0 - shift
+        hist = -(-lookback // n)
+        if hist > _capi.ADSP_MAX_HISTORY:
+            continue
+        cost = f * log_f / v
+        geo = Geometry(f, hist, lookback, j0, shift, v)
+        if optimize_for == "stream":
+            if v >= n:          # one block per call: smallest such transform wins
+                return geo
+            if best is None or cost < best[0]:
+                best = (cost, geo)
+        elif best is None or cost < best[0]:
+            best = (cost, geo)
+    if best is None:
+        raise ValueError(f"a kernel of {m} taps at chunk_size {n} does not fit a 32768-point transform "
+                         "(partitioned convolution is not implemented)")
+    return best[1]
 
 
 def engine_spectrum(fir: FirStream, geo: Geometry, gain: float = 1.0) -> np.ndarray:

@@ -104,6 +104,16 @@ def main():
     kat["EQ128"] = run_device(ref.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), stream(84, 9 * 128), 128)
     ref.config.initialize(44100, 64)
     kat["LC64"] = run_device(ref.CreateLowCutFilter(2000), stream(85, 11 * 64), 64)
+    # chunk sizes that are not powers of two (any N % 4 == 0 works in the reference)
+    ref.config.initialize(44100, 1000)
+    kat["LC1000"] = run_device(ref.CreateLowCutFilter(300), stream(86, 7 * 1000), 1000)
+    kat["EQ1000"] = run_device(ref.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), stream(87, 7 * 1000), 1000)
+    ref.config.initialize(48000, 1920)
+    kat["HC1920"] = run_device(ref.CreateHighCutFilter(9000), stream(88, 5 * 1920), 1920)
+    ref.config.initialize(44100, 12000)
+    kat["LC12000"] = run_device(ref.CreateLowCutFilter(120), stream(89, 3 * 12000), 12000)
+    ref.config.initialize(44100, 20)
+    kat["EQ20"] = run_device(ref.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), stream(90, 40 * 20), 20)
     for k in "ABCD":
         meta["sha_" + k] = hashlib.sha256(kat[k].tobytes()).hexdigest()[:12]
     save("kat_streams", **kat)

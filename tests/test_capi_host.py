@@ -33,9 +33,11 @@ def test_plans_cover_supported_chunk_sizes():
             assert d["threads_per_transform"] * d["points_per_thread"] == f // 2
             assert d["lds_bytes"] == d["channels_per_workgroup"] * (f // 2) * 8 <= 160 * 1024
             assert (n // 4) % (2 * d["threads_per_transform"]) == 0  # design.py's N/4 granularity is legal
-    assert lib.adsp_plan_supported(3000, 6000) != 0
-    assert lib.adsp_plan_supported(32, 64) != 0
-    assert lib.adsp_plan_supported(4096, 4096) != 0
+    assert lib.adsp_plan_supported(3000, 6000) != 0   # transforms are powers of two
+    assert lib.adsp_plan_supported(32, 64) != 0       # ... of at least 128 points
+    assert lib.adsp_plan_supported(3002, 8192) != 0   # chunk must be a multiple of 4
+    assert lib.adsp_plan_supported(3000, 8192) == 0   # generic geometry: any such chunk with any supported transform
+    assert lib.adsp_plan_supported(44100, 32768) == 0
     assert b"chunk_size" in lib.adsp_last_error() or b"fft_size" in lib.adsp_last_error()
 
 

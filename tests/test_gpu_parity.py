@@ -36,6 +36,12 @@ KAT = {
     "HC256": (lambda p: p.CreateHighCutFilter(3000), 44100, 256, 83, 9),
     "EQ128": (lambda p: p.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), 44100, 128, 84, 9),
     "LC64": (lambda p: p.CreateLowCutFilter(2000), 44100, 64, 85, 11),
+    # chunk sizes that are not powers of two run on the generic-geometry kernel
+    "LC1000": (lambda p: p.CreateLowCutFilter(300), 44100, 1000, 86, 7),
+    "EQ1000": (lambda p: p.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), 44100, 1000, 87, 7),
+    "HC1920": (lambda p: p.CreateHighCutFilter(9000), 48000, 1920, 88, 5),
+    "LC12000": (lambda p: p.CreateLowCutFilter(120), 44100, 12000, 89, 3),
+    "EQ20": (lambda p: p.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), 44100, 20, 90, 40),
 }
 
 
@@ -201,6 +207,33 @@ def test_batch_optimised_geometry_eq(adsp, n):
         assert_parity(y[:, c].reshape(-1), o.direct_stream_convolution(taps, x[:, c].reshape(-1), n), what=f"ch {c}")
 
 
+@pytest.mark.parametrize("n,channels", [(20, 37), (1000, 5), (1920, 3), (3000, 4), (12000, 2), (16384, 2), (44100, 1)])
+def test_generic_chunk_sizes_vs_oracle(adsp, n, channels):
+    """Any chunk size divisible by 4: batched channels, per-step and multi-step launches, float32 and int16."""
+    from pyaudiodsptools_amd import FirEngine, FirStream, design
+    o = orc()
+    fs, steps = 44100, 5
+    taps = design.lowcut_kernel(250, fs, n)
+    fir = FirStream(taps, n)
+    rng = np.random.default_rng(n)
+    x = rng.uniform(-1, 1, (steps, channels, n)).astype(np.float32)
+    truth = [o.direct_stream_convolution(taps, x[:, c].reshape(-1), n) for c in range(channels)]
+    for mode in ("stream", "batch"):
+        eng = FirEngine(fir, channels=channels, optimize_for=mode)
+        y_stream = np.stack([eng.apply_host(x[k]) for k in range(steps)])
+        eng.reset()
+        y_multi = np.concatenate([eng.apply_host(x[:2]), eng.apply_host(x[2:])])
+        for c in range(channels):
+            assert_parity(y_stream[:, c].reshape(-1), truth[c], what=f"N={n} {mode} stream ch {c}")
+            assert_parity(y_multi[:, c].reshape(-1), truth[c], what=f"N={n} {mode} multi ch {c}")
+    pcm = rng.integers(-8000, 8000, (steps, channels, n), dtype=np.int16)
+    eng = FirEngine(fir, channels=channels, sample_format="s16")
+    y = eng.apply_host(pcm)
+    for c in range(channels):
+        want = o.float_to_pcm16(o.direct_stream_convolution(taps, o.pcm16_to_float(pcm[:, c].reshape(-1)), n).astype(np.float32))
+        assert np.abs(y[:, c].reshape(-1).astype(np.int32) - want.astype(np.int32)).max() <= 1
+
+
 def test_device_pointer_and_ring_paths(adsp):
     """adsp_apply_device on torch tensors and the zero-copy ring path give the same stream."""
     import torch
@@ -253,9 +286,12 @@ def test_spectrum_update_keeps_history(adsp):
 
 def test_errors_cross_the_abi_as_exceptions(adsp):
     from pyaudiodsptools_amd import _capi
-    adsp.config.initialize(44100, 3000)
+    adsp.config.initialize(44100, 3002)
     with pytest.raises(ValueError):
-        adsp.CreateLowCutFilter(800)  # chunk size without a plan (non power of two): documented limitation
+        adsp.CreateLowCutFilter(800)  # chunk sizes must be multiples of 4
+    adsp.config.initialize(44100, 88200)
+    with pytest.raises(ValueError):
+        adsp.CreateLowCutFilter(800)  # 44099 taps do not fit one 32768-point transform (partitioning: not implemented)
     adsp.config.initialize(44100, 512)
     dev = adsp.CreateLowCutFilter(800, channels=2)
     with pytest.raises(ValueError):
@@ -349,7 +385,7 @@ def test_raw_c_abi_error_paths(adsp):
         h = ctypes.c_void_p()
         return lib.adsp_create(ctypes.byref(cfg), ctypes.byref(h)), h
 
-    for bad in (dict(chunk_size=500), dict(fft_size=512), dict(n_channels=0), dict(history_chunks=0), dict(lookback=641),
+    for bad in (dict(chunk_size=502), dict(fft_size=500), dict(fft_size=65536), dict(n_channels=0), dict(history_chunks=0), dict(lookback=641),
                 dict(lookback=4096), dict(out_offset=1000), dict(out_offset=768, lookback=640), dict(ring_slots=2),
                 dict(device_id=99), dict(sample_format=7)):
         rc, h = create(**bad)

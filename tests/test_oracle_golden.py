@@ -22,6 +22,12 @@ KAT = {
     "HC256": (lambda fs, n: orc.OracleHighCut(3000, fs, n), 44100, 256, 83, 9),
     "EQ128": (lambda fs, n: orc.OracleEQ3BandFFT(100, 2, 700, -4, 8000, 5, fs, n), 44100, 128, 84, 9),
     "LC64": (lambda fs, n: orc.OracleLowCut(2000, fs, n), 44100, 64, 85, 11),
+    # chunk sizes that are not powers of two
+    "LC1000": (lambda fs, n: orc.OracleLowCut(300, fs, n), 44100, 1000, 86, 7),
+    "EQ1000": (lambda fs, n: orc.OracleEQ3BandFFT(100, 2, 700, -4, 8000, 5, fs, n), 44100, 1000, 87, 7),
+    "HC1920": (lambda fs, n: orc.OracleHighCut(9000, fs, n), 48000, 1920, 88, 5),
+    "LC12000": (lambda fs, n: orc.OracleLowCut(120, fs, n), 44100, 12000, 89, 3),
+    "EQ20": (lambda fs, n: orc.OracleEQ3BandFFT(100, 2, 700, -4, 8000, 5, fs, n), 44100, 20, 90, 40),
 }
 SHA = {"A": "a77f6d09f062", "B": "5af354dacc5b", "C": "9084f1fbd924", "D": "e17160836e0f"}
 
@@ -128,14 +134,13 @@ def test_input_types(golden):
 
 
 # ---- independent ground truth: float64 direct convolution (no FFT) -----------------------------
-@pytest.mark.parametrize("name", ["A", "B", "C", "D", "HC256", "EQ128", "LC64", "EQ1024"])
+@pytest.mark.parametrize("name", ["A", "B", "C", "D", "HC256", "EQ128", "LC64", "EQ1024", "LC1000", "EQ1000", "EQ20"])
 def test_direct_convolution_identity(golden, name):
     make, fs, n, seed, chunks = KAT[name]
     x = seeded_stream(seed, chunks * n)
     dev = make(fs, n)
     if isinstance(dev, orc.OracleEQ3BandFFT):
-        params = {"C": (100, 2, 700, -4, 8000, 5), "EQ128": (100, 2, 700, -4, 8000, 5),
-                  "EQ1024": (250, -6, 1500, 3, 6000, -2.5)}[name]
+        params = {"EQ1024": (250, -6, 1500, 3, 6000, -2.5)}.get(name, (100, 2, 700, -4, 8000, 5))
         taps = orc.eq3_composite_taps(*params, fs, n)
     else:
         taps = np.fft.ifft(dev.spectrum).real[: n // 2 - 1]
