@@ -122,6 +122,11 @@ ADSP_API int adsp_set_spectrum_device(adsp_engine* engine, const float* d_spectr
  * larger is cheaper (1.5 N for the cut filters at F = 2N). */
 ADSP_API int adsp_set_block_outputs(adsp_engine* engine, int block_outputs);
 
+/* Partitioned convolution: a kernel longer than one transform is split into parts, one engine per part (each with
+ * the part's taps and delay); engines after the first ADD their partial result to the output buffer instead of
+ * overwriting it.  Generic-geometry float32 engines only (adsp_apply_device / adsp_apply_ring outputs). */
+ADSP_API int adsp_set_accumulate(adsp_engine* engine, int accumulate);
+
 /* Forget all history (a fresh reference device). */
 ADSP_API int adsp_reset(adsp_engine* engine);
 

@@ -13,13 +13,13 @@ from . import config
 from .design import FirStream
 from .devices import (CreateEQ3BandFFT, CreateEQ3BandFFTGPU, CreateHighCutFilter, CreateHighCutFilterGPU,
                       CreateLowCutFilter, CreateLowCutFilterGPU, fuse)
-from .engine import FirEngine
+from .engine import FirEngine, PartitionedFirEngine, make_engine
 from . import wavio as Utility
 from .wavio import (CombineChunks, MakeChunks, MonoWavToNumpy16BitInt, MonoWavToNumpyFloat, NumpyFloatToWav,
                     StereoWavToNumpyFloat, WavBank)
 
 __all__ = ["config", "CreateHighCutFilter", "CreateLowCutFilter", "CreateEQ3BandFFT", "CreateHighCutFilterGPU",
-           "CreateLowCutFilterGPU", "CreateEQ3BandFFTGPU", "FirEngine", "FirStream", "fuse", "Utility", "MakeChunks",
+           "CreateLowCutFilterGPU", "CreateEQ3BandFFTGPU", "FirEngine", "PartitionedFirEngine", "make_engine", "FirStream", "fuse", "Utility", "MakeChunks",
            "CombineChunks", "MonoWavToNumpyFloat", "MonoWavToNumpy16BitInt", "StereoWavToNumpyFloat", "NumpyFloatToWav",
            "WavBank"]
 __version__ = "0.1.0"

@@ -48,6 +48,7 @@ SIGNATURES = {
     "adsp_set_spectrum": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_int]),
     "adsp_set_spectrum_device": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "adsp_set_block_outputs": (ctypes.c_int, [_engine_p, ctypes.c_int]),
+    "adsp_set_accumulate": (ctypes.c_int, [_engine_p, ctypes.c_int]),
     "adsp_reset": (ctypes.c_int, [_engine_p]),
     "adsp_apply_host": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "adsp_apply_device": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),

@@ -144,6 +144,7 @@ struct adsp_engine {
     adsp_config cfg;
     const PlanInfo* plan;
     int M, logN, block_outputs;
+    bool accumulate;  // add to the output instead of overwriting (generic float engines; partitioned FIRs)
     bool generic;  // generic-geometry kernel (chunk not a power of two / F not 2N or 4N)
     char* ring;    // [ring_slots][C][N] samples of cfg.sample_format
     int ring_pos;  // slot of the most recent chunk
@@ -233,6 +234,7 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
     a.N = c.chunk_size;
     a.nh = c.history_chunks;
     a.inv_n = 1.0f / (float)c.chunk_size;
+    a.accumulate = e->accumulate ? 1 : 0;
     const long long total = (long long)n_steps * c.chunk_size;
     if (total + 8LL * c.fft_size >= 0x7fffffffLL)  // the kernel indexes a channel's time axis with 32-bit ints
         return fail(ADSP_ERR_ARG, "n_steps %d x chunk %d is too long for one call; split it", n_steps, c.chunk_size);
@@ -341,6 +343,7 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     e->M = F / 2;
     e->logN = ilog2(N);
     e->generic = generic;
+    e->accumulate = false;
     // samples kept per transform: one chunk for the specialised kernels' single-step launches; the generic kernel
     // always tiles the time axis with block_outputs (default: as many whole segments as the transform offers)
     e->block_outputs = generic ? (F - cfg->out_offset) / (2 * T2) * (2 * T2) : N;
@@ -440,6 +443,14 @@ int adsp_set_block_outputs(adsp_engine* e, int v) {
     // newest input used by the block = o - lookback + F - 1 may exceed the data, that part is zero-filled and
     // only feeds discarded circular positions as long as out_offset + V <= F (checked above).
     e->block_outputs = v;
+    return ADSP_OK;
+}
+
+int adsp_set_accumulate(adsp_engine* e, int on) {
+    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    if (on && (!e->generic || e->cfg.sample_format != ADSP_FORMAT_F32))
+        return fail(ADSP_ERR_ARG, "accumulating output needs a generic-geometry float32 engine");
+    e->accumulate = on != 0;
     return ADSP_OK;
 }
 

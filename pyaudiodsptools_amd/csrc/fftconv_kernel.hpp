@@ -75,6 +75,7 @@ struct KernelArgs {
     int N;                 // chunk size (generic-geometry kernel only; the specialised kernels know it at compile time)
     int nh;                // history chunks (generic-geometry kernel only)
     float inv_n;           // 1 / N
+    int accumulate;        // generic float kernel: add the kept samples to `out` instead of overwriting (partitioned FIRs)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -973,7 +974,8 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_generic_ke
                     __builtin_nontemporal_store(v, reinterpret_cast<v2u*>(dst));
                 } else {
                     typedef float v4f __attribute__((ext_vector_type(4)));
-                    const v4f v = odd ? v4f{sx, sy, xr[2 * u + 1], xi[2 * u + 1]} : v4f{xr[2 * u], xi[2 * u], sx, sy};
+                    v4f v = odd ? v4f{sx, sy, xr[2 * u + 1], xi[2 * u + 1]} : v4f{xr[2 * u], xi[2 * u], sx, sy};
+                    if (a.accumulate) v += *reinterpret_cast<const v4f*>(dst);  // partial sum of an earlier partition
                     __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(dst));
                 }
             }

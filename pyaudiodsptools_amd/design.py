@@ -192,6 +192,27 @@ def _generic_geometry(fir: FirStream, fft_mult: int, optimize_for: str) -> Geome
     return best[1]
 
 
+def fits_one_transform(fir: FirStream) -> bool:
+    try:
+        overlap_save_geometry(fir)
+        return True
+    except ValueError:
+        return False
+
+
+def partition(fir: FirStream, max_taps: int = 14336):
+    """Split a long kernel into parts that each fit one transform: out = sum_p conv(part_p, x delayed by p*max_taps).
+
+    Part p keeps the chunk size and latency and moves the look-ahead back by p*max_taps samples (delays add), so every
+    part is an ordinary FirStream for its own engine; results are summed (adsp_set_accumulate)."""
+    m = len(fir.taps)
+    parts = []
+    for p in range(-(-m // max_taps)):
+        sl = fir.taps[p * max_taps:(p + 1) * max_taps]
+        parts.append(FirStream(sl, fir.chunk_size, fir.latency_chunks, fir.lookahead - p * max_taps))
+    return parts
+
+
 def engine_spectrum(fir: FirStream, geo: Geometry, gain: float = 1.0) -> np.ndarray:
     """rfft of the (shift-delayed) kernel at F points, float64 -> complex64, as interleaved float32.
 

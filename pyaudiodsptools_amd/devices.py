@@ -20,7 +20,7 @@ import numpy as np
 from . import config
 from .design import (FirStream, eq3_composite, eq3_kernels, filter_length, highcut_kernel, lowcut_kernel,
                      reference_spectrum_3n)
-from .engine import FirEngine
+from .engine import FirEngine, make_engine
 
 
 class _FFTDevice:
@@ -37,7 +37,7 @@ class _FFTDevice:
         self.array_slice_value_end = self._n - (self.filter_length // 2)
         self.cut_size = np.int16((self.filter_length - 1) / 2)
         self.fir = FirStream(fir_taps, self._n, latency_chunks=1, lookahead=d)
-        self.engine = FirEngine(self.fir, channels=self.channels, device=device)
+        self.engine = make_engine(self.fir, channels=self.channels, device=device)
         zeros = np.zeros(self._n) if self.channels == 1 else np.zeros((self.channels, self._n))
         self.float32_array_input_1 = zeros
         self.float32_array_input_2 = zeros

@@ -9,7 +9,7 @@ import ctypes
 import numpy as np
 
 from . import _capi
-from .design import PCM16_GAIN, FirStream, engine_spectrum, overlap_save_geometry
+from .design import PCM16_GAIN, FirStream, engine_spectrum, fits_one_transform, overlap_save_geometry, partition
 
 _FORMATS = {"f32": (_capi.ADSP_FORMAT_F32, np.float32), "s16": (_capi.ADSP_FORMAT_S16, np.int16)}
 
@@ -83,6 +83,10 @@ class FirEngine:
     def upload_spectrum_device(self, d_spectrum, n_bins, stream=None):
         _capi.check(self._lib.adsp_set_spectrum_device(self._h, _ptr(d_spectrum), int(n_bins), _ptr(stream)))
 
+    def set_accumulate(self, on=True):
+        """Add results to the output buffer instead of overwriting it (later parts of a partitioned FIR)."""
+        _capi.check(self._lib.adsp_set_accumulate(self._h, 1 if on else 0))
+
     def set_block_outputs(self, v):
         _capi.check(self._lib.adsp_set_block_outputs(self._h, int(v)))
         self.block_outputs = int(v)
@@ -141,3 +145,58 @@ class FirEngine:
 
     def synchronize(self, stream=None):
         _capi.check(self._lib.adsp_synchronize(self._h, _ptr(stream)))
+
+
+class PartitionedFirEngine:
+    """A FIR too long for one 32768-point transform (e.g. the reference's Example4: chunk 88200, 44099 taps), run as
+    P ordinary engines over the same input - one per slice of the kernel, each with the slice's extra delay - whose
+    partial outputs are summed.  Same call surface as FirEngine for the float32 paths."""
+
+    def __init__(self, fir: FirStream, channels=1, device=0, max_taps=14336, optimize_for="stream"):
+        self.fir = fir
+        self.parts = partition(fir, max_taps)
+        self.engines = [FirEngine(p, channels=channels, device=device, optimize_for=optimize_for) for p in self.parts]
+        for eng in self.engines[1:]:
+            eng.set_accumulate(True)
+        self.channels, self.chunk_size, self.device = int(channels), int(fir.chunk_size), int(device)
+        self.geometry = self.engines[0].geometry
+        self.sample_format = "f32"
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+
+    def reset(self):
+        for e in self.engines:
+            e.reset()
+
+    def apply_device(self, d_in, d_out, n_steps=1, stream=None):
+        for e in self.engines:  # stream-ordered: part 0 overwrites, the others add
+            e.apply_device(d_in, d_out, n_steps, stream)
+
+    def apply_host(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        # host path: each part through its own staging buffers, summed in float64 and rounded once
+        acc = None
+        for e in self.engines:
+            e.set_accumulate(False)
+            y = e.apply_host(x).astype(np.float64)
+            acc = y if acc is None else acc + y
+        for e in self.engines[1:]:
+            e.set_accumulate(True)
+        return acc.astype(np.float32)
+
+    def synchronize(self, stream=None):
+        self.engines[0].synchronize(stream)
+
+
+def make_engine(fir: FirStream, **kw):
+    """FirEngine when the kernel fits one transform, PartitionedFirEngine otherwise."""
+    if fits_one_transform(fir):
+        return FirEngine(fir, **kw)
+    if kw.get("sample_format", "f32") != "f32":
+        raise ValueError("kernels longer than one transform are supported for float32 samples only")
+    kw.pop("sample_format", None)
+    kw.pop("ring_slots", None)
+    kw.pop("fft_mult", None)
+    return PartitionedFirEngine(fir, **kw)

@@ -114,6 +114,10 @@ def main():
     kat["LC12000"] = run_device(ref.CreateLowCutFilter(120), stream(89, 3 * 12000), 12000)
     ref.config.initialize(44100, 20)
     kat["EQ20"] = run_device(ref.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), stream(90, 40 * 20), 20)
+    # Example4's chunk size (88200 = 2 s at 44.1 kHz, 44099 taps): every 64th output sample of 3 chunks
+    ref.config.initialize(44100, 88200)
+    kat["LC88200_dec64"] = run_device(ref.CreateLowCutFilter(300), stream(91, 3 * 88200), 88200)[::64].copy()
+    kat["EQ88200_dec64"] = run_device(ref.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), stream(92, 3 * 88200), 88200)[::64].copy()
     for k in "ABCD":
         meta["sha_" + k] = hashlib.sha256(kat[k].tobytes()).hexdigest()[:12]
     save("kat_streams", **kat)

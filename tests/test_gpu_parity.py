@@ -234,6 +234,34 @@ def test_generic_chunk_sizes_vs_oracle(adsp, n, channels):
         assert np.abs(y[:, c].reshape(-1).astype(np.int32) - want.astype(np.int32)).max() <= 1
 
 
+def test_example4_chunk_size_partitioned(adsp, golden):
+    """N = 88200 (Example4.py:5): 44099 / 88197 taps do not fit one transform -> partitioned engines, summed.
+    Drop-in classes against the reference's decimated goldens; the device path (accumulating launches) against the
+    host path."""
+    import torch
+    n = 88200
+    adsp.config.initialize(44100, n)
+    for dev, seed, key in ((adsp.CreateLowCutFilter(300), 91, "LC88200_dec64"),
+                           (adsp.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), 92, "EQ88200_dec64")):
+        assert type(dev.engine).__name__ == "PartitionedFirEngine" and len(dev.engine.engines) >= 4
+        x = seeded_stream(seed, 3 * n)
+        y = np.concatenate([dev.apply(x[i * n:(i + 1) * n]) for i in range(3)])
+        assert_parity(y[::64], golden["kat_streams"][key], what=key)
+        dev.reset()
+        xd = torch.from_numpy(x.reshape(3, 1, n)).cuda()
+        yd = torch.full_like(xd, 7.0)  # part 0 must overwrite, the others accumulate
+        s = torch.cuda.current_stream().cuda_stream
+        dev.engine.apply_device(xd[:2], yd[:2], 2, s)
+        dev.engine.apply_device(xd[2], yd[2], 1, s)
+        torch.cuda.synchronize()
+        assert_parity(yd.cpu().numpy().reshape(-1), y, what=key + " device path")
+    adsp.config.initialize(44100, 88200)
+    with pytest.raises(ValueError):
+        adsp.FirEngine(dev.fir, sample_format="s16")  # one engine cannot hold it ...
+    with pytest.raises(ValueError):
+        adsp.make_engine(dev.fir, sample_format="s16")  # ... and partitioning is float32 only
+
+
 def test_device_pointer_and_ring_paths(adsp):
     """adsp_apply_device on torch tensors and the zero-copy ring path give the same stream."""
     import torch
@@ -289,9 +317,6 @@ def test_errors_cross_the_abi_as_exceptions(adsp):
     adsp.config.initialize(44100, 3002)
     with pytest.raises(ValueError):
         adsp.CreateLowCutFilter(800)  # chunk sizes must be multiples of 4
-    adsp.config.initialize(44100, 88200)
-    with pytest.raises(ValueError):
-        adsp.CreateLowCutFilter(800)  # 44099 taps do not fit one 32768-point transform (partitioning: not implemented)
     adsp.config.initialize(44100, 512)
     dev = adsp.CreateLowCutFilter(800, channels=2)
     with pytest.raises(ValueError):

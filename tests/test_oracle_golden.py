@@ -47,6 +47,15 @@ def test_literal_oracle_matches_reference_streams(golden, name):
         assert hashlib.sha256(y.tobytes()).hexdigest()[:12] == SHA[name]
 
 
+def test_example4_chunk_size_decimated(golden):
+    """N = 88200 (Example4.py:5): the oracle against every 64th sample the reference produced."""
+    n = 88200
+    y = run(orc.OracleLowCut(300, 44100, n), seeded_stream(91, 3 * n), n)
+    assert np.array_equal(y[::64], golden["kat_streams"]["LC88200_dec64"])
+    y = run(orc.OracleEQ3BandFFT(100, 2, 700, -4, 8000, 5, 44100, n), seeded_stream(92, 3 * n), n)
+    assert np.array_equal(y[::64], golden["kat_streams"]["EQ88200_dec64"])
+
+
 def test_survey_spot_values(golden):
     y = golden["kat_streams"]["A"]
     assert np.allclose(y[2 * 4096:2 * 4096 + 4], [-0.6452144, -0.29364097, 0.22403768, 0.04141868], atol=1e-7)
