@@ -203,11 +203,16 @@ def main():
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (pyaudiodsptools_amd has no CPU path)")
+    # test hooks (single-GPU boxes): ADSP_BENCH_SINGLE_DEVICE=1 puts every rank on GPU 0, ADSP_BENCH_BACKEND=gloo
+    # replaces RCCL - lets the N > 1 control flow run where only one GPU exists.  Never set by the driver.
+    if os.environ.get("ADSP_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("ADSP_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     barrier = None
     if world > 1:
-        adist.init_process_group("nccl")
+        adist.init_process_group(backend)
         import torch.distributed as tdist
         barrier = tdist.barrier
 
@@ -217,7 +222,7 @@ def main():
     main_run = Runner(args, args.mode, fir, dev, local_rank, world, rank)
     steps, warm, wall, kern_ms, launches = main_run.measure(args.steps, args.warmup, barrier)
     if world > 1:
-        t = torch.tensor([wall, kern_ms], device=dev, dtype=torch.float64)
+        t = torch.tensor([wall, kern_ms], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         wall, kern_ms = float(t[0]), float(t[1])
 
