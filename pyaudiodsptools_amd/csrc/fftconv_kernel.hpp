@@ -11,22 +11,27 @@
 // a plain linear convolution, so a 2N real transform packed as N complex
 // points is exact and 3x cheaper.
 //
-// Design notes (CDNA4):
+// Design notes (CDNA4, all measured on MI355X - see DESIGN.md section 3/5 and micro/):
 //  * wave64; every thread owns P (16 or 32) complex points in VGPRs, element index tid + T*m.
 //    Every Stockham pass reads elements  j + q*M/R  (= the thread's own registers) and writes runs
 //    of S contiguous elements to LDS, so reads are always bank-conflict-free (64 consecutive
 //    8-byte elements per wave) and only the S=1 pass needs an XOR swizzle on the write side.
 //  * ds_read_b64/ds_write_b64 on interleaved (re,im) pairs; one LDS buffer of M*8 bytes per
-//    transform (32 KiB at N = 4096 -> 5 workgroups per CU).
-//  * the real-FFT split needs Z[k] and Z[M-k] together.  The last forward pass (radix P/2, two
-//    butterflies per thread) is given butterflies j and M/R - j, so both partners are produced in
-//    the same thread: the split + spectrum multiply + re-pack costs no exchange at all, and the
-//    first inverse pass consumes exactly that register distribution.
+//    transform (32 KiB at N = 4096).
+//  * the real-FFT split needs Z[k] and Z[M-k] together.  In-register plans give the last forward pass
+//    (radix P/2, two butterflies per thread) butterflies j and M/R - j, so both partners are produced in
+//    the same thread; the "XL" plan (M = 4096: P = 16, 256 threads, three radix-16 passes) keeps one
+//    butterfly per thread and exchanges half of the registers between lanes l and l^32 with
+//    v_permlane32_swap.  Either way split + spectrum multiply + re-pack is ONE 2x2 complex matrix per bin
+//    pair (pair_op, 16 multiply-adds) and needs no LDS exchange.
 //  * inverse FFT = forward FFT on (im, re)-swapped registers: one set of butterflies, one sign.
-//  * global loads/stores are 8 bytes per lane, 512 contiguous bytes per wave instruction; chunk
-//    selection (ring history vs. the new batch) is wave-uniform scalar work.
-//  * no MFMA: ~100 flop/sample against 8-10 B/sample of HBM traffic, the walls are HBM, LDS
-//    write bandwidth and fp32 VALU in that order.
+//  * radix-16 pass twiddles are two-level: 6 loaded, 9 formed in registers (w^(4a+b) = w^(4a) w^b).
+//  * global accesses are 16 bytes per lane (8 for int16 PCM) with a DPP swap between neighbouring lanes -
+//    a dwordx2 costs the TA exactly what a dwordx4 does; chunk selection (ring history vs. the new batch)
+//    is resolved once per block into <= F/N + 1 pointers; output stores are non-temporal.
+//  * no packed f32 math (half rate on gfx950), no MFMA (no contraction): ~100 flop/sample against
+//    8-10 B/sample; sustained multi-step launches are power-limited (clock ~1.7 GHz), single-step
+//    launches latency-bound at 2.45 GHz.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
