@@ -433,3 +433,43 @@ def test_raw_c_abi_error_paths(adsp):
     assert lib.adsp_enable_kernel_timing(h, 1) == 0 and lib.adsp_apply_host(h, buf, buf, 2) == 0
     assert lib.adsp_kernel_time(h, ctypes.byref(ms), ctypes.byref(n)) == 0 and n.value == 1 and ms.value > 0
     assert lib.adsp_destroy(h) == 0 and lib.adsp_destroy(None) == 0
+
+
+@pytest.mark.parametrize("n,kind", [(256, "lowcut"), (1024, "eq"), (1000, "lowcut")])
+def test_soak_mixed_call_types_ring_wrap(adsp, n, kind):
+    """60 steps through one engine with every entry point interleaved (host single/multi-step, device single/multi-step,
+    zero-copy ring): the history ring wraps many times, side-stream copies overlap kernels; one oracle stream."""
+    import ctypes
+    import torch
+    from pyaudiodsptools_amd import FirEngine, FirStream, design
+    o = orc()
+    fs, channels, steps = 44100, 3, 60
+    taps = design.lowcut_kernel(500, fs, n) if kind == "lowcut" else design.eq3_composite(100, 2, 700, -4, 8000, 5, fs, n)
+    eng = FirEngine(FirStream(taps, n), channels=channels, ring_slots=5)
+    rng = np.random.default_rng(n)
+    x = rng.uniform(-1, 1, (steps, channels, n)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.zeros_like(xd)
+    s = torch.cuda.current_stream().cuda_stream
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    k, pattern = 0, ["host1", "dev3", "ring", "dev1", "host4", "ring", "ring", "dev5", "host1", "dev2"]
+    i = 0
+    while k < steps:
+        op = pattern[i % len(pattern)]
+        i += 1
+        cnt = min(int(op[-1]) if op[-1].isdigit() else 1, steps - k)
+        if op.startswith("host"):
+            torch.cuda.synchronize()
+            yd[k:k + cnt] = torch.from_numpy(eng.apply_host(x[k:k + cnt])).cuda()
+        elif op.startswith("dev"):
+            eng.apply_device(xd[k:k + cnt], yd[k:k + cnt], cnt, s)
+        else:
+            slot = eng.ring_acquire()
+            assert hip.hipMemcpyAsync(slot, xd[k].data_ptr(), channels * n * 4, 3, s) == 0
+            eng.apply_ring(yd[k], s)
+        k += cnt
+    torch.cuda.synchronize()
+    y = yd.cpu().numpy()
+    for c in range(channels):
+        assert_parity(y[:, c].reshape(-1), o.direct_stream_convolution(taps, x[:, c].reshape(-1), n), what=f"N={n} ch {c}")
