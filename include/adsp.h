@@ -29,6 +29,8 @@
 #ifndef ADSP_H
 #define ADSP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -121,6 +123,24 @@ ADSP_API int adsp_set_spectrum_device(adsp_engine* engine, const float* d_spectr
  * chunk_size; any multiple of 2*threads_per_transform up to fft_size - out_offset is valid and
  * larger is cheaper (1.5 N for the cut filters at F = 2N). */
 ADSP_API int adsp_set_block_outputs(adsp_engine* engine, int block_outputs);
+
+/* Stateless effects, fused on the filter kernel's output registers (no extra HBM traffic) or run as a
+ * standalone elementwise kernel.  Formulas and parameter meaning follow the reference:
+ *   VOLUME           Utility.py:171-194 VolumeChange          p0 = 10^(dB/20), p1 != 0 clips to [-1, 1]
+ *   SOFT_CLIPPER     EffectSoftClipper.py:23-45               p0 = drive + 1
+ *   HARD_DISTORTION  EffectHardDistortion.py:17-41            (no parameters)
+ *   SATURATOR        EffectSaturator.py:16-49                 p0 = 10^(threshold_dB/20), p1 = 10^(makeup_dB/20), p2 = 1 hard / 2 soft */
+#define ADSP_EFFECT_NONE 0
+#define ADSP_EFFECT_VOLUME 1
+#define ADSP_EFFECT_SOFT_CLIPPER 2
+#define ADSP_EFFECT_HARD_DISTORTION 3
+#define ADSP_EFFECT_SATURATOR 4
+/* every later apply of a float32 engine returns effect(filter(x)); ADSP_EFFECT_NONE removes it */
+ADSP_API int adsp_set_epilogue(adsp_engine* engine, int effect, float p0, float p1, float p2);
+/* out[i] = effect(in[i]) on device / host float32 arrays of n values (in-place allowed) */
+ADSP_API int adsp_effect_device(int device_id, int effect, float p0, float p1, float p2, const float* d_in, float* d_out,
+                                size_t n, void* stream);
+ADSP_API int adsp_effect_host(int device_id, int effect, float p0, float p1, float p2, const float* in, float* out, size_t n);
 
 /* Partitioned convolution: a kernel longer than one transform is split into parts, one engine per part (each with
  * the part's taps and delay); engines after the first ADD their partial result to the output buffer instead of

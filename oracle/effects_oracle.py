@@ -1,0 +1,49 @@
+"""CPU oracle for the stateless wave-shapers.  TEST INFRASTRUCTURE ONLY - see fftfilter_oracle.py.
+
+numpy restatement, in float32 like the reference computes when it is handed float32 chunks (numpy >= 2 keeps python
+scalars "weak", so every intermediate stays float32).  Pinned against tests/golden/kat_effects.npz, captured from the
+real reference by tests/golden/make_golden.py.
+
+Reference anchors:
+  * soft clipper      pyAudioDspTools/EffectSoftClipper.py:18-45
+  * hard distortion   pyAudioDspTools/EffectHardDistortion.py:14-41
+  * saturator         pyAudioDspTools/EffectSaturator.py:19-49
+  * volume change     pyAudioDspTools/Utility.py:171-194
+"""
+import numpy as np
+
+F = np.float32
+
+
+def soft_clipper(x, drive=0.44):
+    x = np.asarray(x, F)
+    a = np.minimum(np.abs(x), F(1))
+    shaped = F(1) - np.power(np.abs(a - F(1)), F(drive + 1))
+    return np.where(x < 0, -shaped, shaped).astype(F)
+
+
+def hard_distortion(x):
+    x = np.asarray(x, F)
+    sign = np.where(x >= 0, F(1), F(-1))
+    a = np.abs(x)
+    a = np.where(a <= F(0.8), a, sign)  # the sign, not 1.0: loud negative samples land on -1 (reference quirk)
+    scale = F(1.0 - 0.8)
+    return ((F(0.8) + scale * np.sin((a - F(0.8)) / scale)) * sign).astype(F)
+
+
+def saturator(x, saturation_threshold_in_db=-20.0, makeup_gain=2.0, mode="hard"):
+    x = np.asarray(x, F)
+    c = F(10 ** (saturation_threshold_in_db / 20))
+    power = {"hard": 1, "soft": 2}[mode]
+    a = np.abs(x)
+    u = a - c
+    with np.errstate(all="ignore"):
+        knee = c + u / (F(1) + (u / (F(1) - c)) ** power)
+    a = np.where(a > c, knee, a)
+    a = np.where(a > F(1), (c + F(1)) / F(2), a)
+    return (F(10 ** (makeup_gain / 20)) * np.where(x < 0, -a, a)).astype(F)
+
+
+def volume_change(x, gain_change_in_db, overflow_protection=True):
+    y = F(10 ** (gain_change_in_db / 20)) * np.asarray(x, F)
+    return np.clip(y, F(-1), F(1)) if overflow_protection else y

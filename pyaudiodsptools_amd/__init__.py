@@ -13,6 +13,8 @@ from . import config
 from .design import FirStream
 from .devices import (CreateEQ3BandFFT, CreateEQ3BandFFTGPU, CreateHighCutFilter, CreateHighCutFilterGPU,
                       CreateLowCutFilter, CreateLowCutFilterGPU, fuse)
+from .effects import (CreateHardDistortion, CreateSaturator, CreateSoftClipper, CreateVolumeChange, Effect,
+                      VolumeChange)
 from .engine import FirEngine, PartitionedFirEngine, make_engine
 from . import wavio as Utility
 from .wavio import (CombineChunks, MakeChunks, MonoWavToNumpy16BitInt, MonoWavToNumpyFloat, NumpyFloatToWav,
@@ -21,5 +23,6 @@ from .wavio import (CombineChunks, MakeChunks, MonoWavToNumpy16BitInt, MonoWavTo
 __all__ = ["config", "CreateHighCutFilter", "CreateLowCutFilter", "CreateEQ3BandFFT", "CreateHighCutFilterGPU",
            "CreateLowCutFilterGPU", "CreateEQ3BandFFTGPU", "FirEngine", "PartitionedFirEngine", "make_engine", "FirStream", "fuse", "Utility", "MakeChunks",
            "CombineChunks", "MonoWavToNumpyFloat", "MonoWavToNumpy16BitInt", "StereoWavToNumpyFloat", "NumpyFloatToWav",
-           "WavBank"]
+           "WavBank", "CreateSoftClipper", "CreateHardDistortion", "CreateSaturator", "VolumeChange", "CreateVolumeChange",
+           "Effect"]
 __version__ = "0.1.0"

@@ -16,6 +16,14 @@
 #include "../../include/adsp.h"
 #include "plan_table.hpp"
 
+// standalone elementwise form of the fused output effects (fftconv_kernel.hpp::epilogue_value): out[i] = effect(in[i])
+__global__ void adsp_pointwise_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n, int op, float p0,
+                                      float p1, float p2) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = adsp::epilogue_value(in[i], op, p0, p1, p2);
+}
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -144,6 +152,8 @@ struct adsp_engine {
     adsp_config cfg;
     const PlanInfo* plan;
     int M, logN, block_outputs;
+    int epi_op;       // fused output effect (ADSP_EFFECT_*), 0 = none
+    float epi_p[3];
     bool accumulate;  // add to the output instead of overwriting (generic float engines; partitioned FIRs)
     bool generic;  // generic-geometry kernel (chunk not a power of two / F not 2N or 4N)
     char* ring;    // [ring_slots][C][N] samples of cfg.sample_format
@@ -235,6 +245,10 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
     a.nh = c.history_chunks;
     a.inv_n = 1.0f / (float)c.chunk_size;
     a.accumulate = e->accumulate ? 1 : 0;
+    a.epi_op = e->epi_op;
+    a.epi_p0 = e->epi_p[0];
+    a.epi_p1 = e->epi_p[1];
+    a.epi_p2 = e->epi_p[2];
     const long long total = (long long)n_steps * c.chunk_size;
     if (total + 8LL * c.fft_size >= 0x7fffffffLL)  // the kernel indexes a channel's time axis with 32-bit ints
         return fail(ADSP_ERR_ARG, "n_steps %d x chunk %d is too long for one call; split it", n_steps, c.chunk_size);
@@ -344,6 +358,8 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     e->logN = ilog2(N);
     e->generic = generic;
     e->accumulate = false;
+    e->epi_op = 0;
+    e->epi_p[0] = e->epi_p[1] = e->epi_p[2] = 0.f;
     // samples kept per transform: one chunk for the specialised kernels' single-step launches; the generic kernel
     // always tiles the time axis with block_outputs (default: as many whole segments as the transform offers)
     e->block_outputs = generic ? (F - cfg->out_offset) / (2 * T2) * (2 * T2) : N;
@@ -443,6 +459,59 @@ int adsp_set_block_outputs(adsp_engine* e, int v) {
     // newest input used by the block = o - lookback + F - 1 may exceed the data, that part is zero-filled and
     // only feeds discarded circular positions as long as out_offset + V <= F (checked above).
     e->block_outputs = v;
+    return ADSP_OK;
+}
+
+int adsp_set_epilogue(adsp_engine* e, int effect, float p0, float p1, float p2) {
+    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    if (effect < ADSP_EFFECT_NONE || effect > ADSP_EFFECT_SATURATOR) return fail(ADSP_ERR_ARG, "unknown effect %d", effect);
+    if (effect != ADSP_EFFECT_NONE && e->cfg.sample_format != ADSP_FORMAT_F32)
+        return fail(ADSP_ERR_ARG, "fused effects need a float32 engine");
+    e->epi_op = effect;
+    e->epi_p[0] = p0;
+    e->epi_p[1] = p1;
+    e->epi_p[2] = p2;
+    return ADSP_OK;
+}
+
+namespace {
+int pointwise_launch(int device_id, int effect, float p0, float p1, float p2, const float* d_in, float* d_out, size_t n,
+                     hipStream_t stream) {
+    if (effect < ADSP_EFFECT_NONE || effect > ADSP_EFFECT_SATURATOR) return fail(ADSP_ERR_ARG, "unknown effect %d", effect);
+    HIP_TRY(hipSetDevice(device_id));
+    if (n == 0) return ADSP_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;  // grid-stride beyond 8 workgroups per CU
+    hipLaunchKernelGGL(adsp_pointwise_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_in, d_out, n, effect, p0, p1, p2);
+    HIP_TRY(hipGetLastError());
+    return ADSP_OK;
+}
+}  // namespace
+
+int adsp_effect_device(int device_id, int effect, float p0, float p1, float p2, const float* d_in, float* d_out,
+                       size_t n, void* stream) {
+    if (!d_in || !d_out) return fail(ADSP_ERR_ARG, "NULL argument");
+    return pointwise_launch(device_id, effect, p0, p1, p2, d_in, d_out, n, (hipStream_t)stream);
+}
+
+int adsp_effect_host(int device_id, int effect, float p0, float p1, float p2, const float* in, float* out, size_t n) {
+    if (!in || !out) return fail(ADSP_ERR_ARG, "NULL argument");
+    int ndev = 0;
+    int rc = adsp_device_count(&ndev);
+    if (rc) return rc;
+    if (device_id < 0 || device_id >= ndev) return fail(ADSP_ERR_ARG, "device_id %d out of range (%d devices)", device_id, ndev);
+    HIP_TRY(hipSetDevice(device_id));
+    if (n == 0) return ADSP_OK;
+    float* d = nullptr;
+    HIP_TRY(hipMalloc(&d, n * sizeof(float)));
+    hipError_t err = hipMemcpy(d, in, n * sizeof(float), hipMemcpyHostToDevice);
+    if (err == hipSuccess) {
+        rc = pointwise_launch(device_id, effect, p0, p1, p2, d, d, n, nullptr);
+        if (rc == ADSP_OK) err = hipMemcpy(out, d, n * sizeof(float), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d);
+    if (rc) return rc;
+    if (err != hipSuccess) return fail(ADSP_ERR_HIP, "effect copy failed: %s", hipGetErrorString(err));
     return ADSP_OK;
 }
 

@@ -80,6 +80,8 @@ struct KernelArgs {
     int N;                 // chunk size (generic-geometry kernel only; the specialised kernels know it at compile time)
     int nh;                // history chunks (generic-geometry kernel only)
     float inv_n;           // 1 / N
+    int epi_op;            // fused output epilogue (0 = none), see apply_epilogue
+    float epi_p0, epi_p1, epi_p2;
     int accumulate;        // generic float kernel: add the kept samples to `out` instead of overwriting (partitioned FIRs)
 };
 
@@ -724,6 +726,58 @@ __device__ __forceinline__ void store_kept_s16(unsigned* const (&ob)[FN + 1], co
 }
 
 // ------------------------------------------------------------------------------------------
+// Stateless effects fused on the output registers - zero extra HBM traffic.  Formulas follow the
+// reference exactly, quirks included:
+//   1 VolumeChange      Utility.py:189-194          y = g x, optionally clipped to [-1, 1]        (p0 = g, p1 = clip flag)
+//   2 CreateSoftClipper EffectSoftClipper.py:38-45  y = sgn(x) (1 - |min(|x|,1) - 1|^p0)         (p0 = drive + 1)
+//   3 CreateHardDistortion EffectHardDistortion.py:30-41  (0.8 + 0.2 sin((a - 0.8)/0.2)) sgn, with a = |x| if |x| <= 0.8
+//                       else sgn(x) (so x < -0.8 lands on sin(-9): the reference's asymmetry is kept)
+//   4 CreateSaturator   EffectSaturator.py:41-49    knee above p0, (p0+1)/2 above 1, makeup p1, mode p2 (1 hard, 2 soft)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float epilogue_value(float x, int op, float p0, float p1, float p2) {
+    switch (op) {
+        case 1: {
+            float y = p0 * x;
+            return p1 != 0.f ? fminf(fmaxf(y, -1.f), 1.f) : y;
+        }
+        case 2: {
+            const float a = fminf(fabsf(x), 1.f);
+            const float t = 1.f - __powf(fabsf(a - 1.f), p0);
+            return x < 0.f ? -t : t;
+        }
+        case 3: {
+            const float sgn = x >= 0.f ? 1.f : -1.f;
+            float a = fabsf(x);
+            a = a <= 0.8f ? a : sgn;
+            const float comp = 0.2f * __sinf((a - 0.8f) / 0.2f);
+            return (0.8f + comp) * sgn;
+        }
+        case 4: {
+            float a = fabsf(x);
+            if (a > p0) {
+                const float u = a - p0;
+                float r = u / (1.f - p0);
+                r = p2 == 2.f ? r * r : r;
+                a = p0 + u / (1.f + r);
+            }
+            if (a > 1.f) a = (p0 + 1.f) * 0.5f;
+            return (x < 0.f ? -a : a) * p1;
+        }
+        default: return x;
+    }
+}
+
+template <int P>
+__device__ __forceinline__ void apply_epilogue(float (&xr)[P], float (&xi)[P], const KernelArgs& a) {
+    if (a.epi_op == 0) return;  // wave-uniform
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+        xr[m] = epilogue_value(xr[m], a.epi_op, a.epi_p0, a.epi_p1, a.epi_p2);
+        xi[m] = epilogue_value(xi[m], a.epi_op, a.epi_p0, a.epi_p1, a.epi_p2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // the transform core shared by both kernels: forward FFT -> spectrum stage -> inverse FFT, in registers + LDS
 // ------------------------------------------------------------------------------------------
 template <class PL>
@@ -834,6 +888,7 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(con
     }
 
     transform_block<PL>(xr, xi, lds, a, tid);
+    if constexpr (!S16) apply_epilogue<P>(xr, xi, a);
 
     // kept samples: circular indices [j0, j0 + keep) -> registers m_lo <= m < m_hi; register m holds
     // output-time o - j0 + 2T*m.  s = o - j0 may be negative: split into chunk part and phase.
@@ -950,6 +1005,7 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_generic_ke
     }
 
     transform_block<PL>(xr, xi, lds, a, tid);
+    if constexpr (!S16) apply_epilogue<P>(xr, xi, a);
 
     const long long total_ll = static_cast<long long>(a.n_steps) * N;
     const int total = static_cast<int>(total_ll);

@@ -20,6 +20,7 @@ import numpy as np
 from . import config
 from .design import (FirStream, eq3_composite, eq3_kernels, filter_length, highcut_kernel, lowcut_kernel,
                      reference_spectrum_3n)
+from .effects import Effect
 from .engine import FirEngine, make_engine
 
 
@@ -150,9 +151,17 @@ def fuse(*devices, channels=None, device=0, ring_slots=0):
 
     The result computes, in a single kernel per step, what feeding each device's output into the
     next one's apply() computes in the reference: one FIR of summed length, latency = number of
-    devices chunks."""
+    devices chunks.  A stateless effect (effects.CreateSoftClipper, ...) may follow the last device; it is applied to
+    the kernel's output registers (no extra pass)."""
+    devices = list(devices)
+    effect = devices.pop() if isinstance(devices[-1], Effect) else None
+    if not devices or any(isinstance(dev, Effect) for dev in devices):
+        raise ValueError("fuse() takes FFT devices, optionally followed by ONE stateless effect at the end")
     fir = devices[0].fir
     for dev in devices[1:]:
         fir = fir.then(dev.fir)
     ch = devices[0].channels if channels is None else channels
-    return FirEngine(fir, channels=ch, device=device, ring_slots=ring_slots)
+    engine = FirEngine(fir, channels=ch, device=device, ring_slots=ring_slots)
+    if effect is not None:
+        engine.set_epilogue(effect)
+    return engine

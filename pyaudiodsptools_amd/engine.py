@@ -53,6 +53,7 @@ class FirEngine:
         self.set_fir(fir)
         self.block_outputs = self.chunk_size
         self.set_block_outputs(geo.max_block_outputs)
+        self.epilogue = None
 
     # -- lifetime -----------------------------------------------------------------------------
     def close(self):
@@ -86,6 +87,13 @@ class FirEngine:
     def set_accumulate(self, on=True):
         """Add results to the output buffer instead of overwriting it (later parts of a partitioned FIR)."""
         _capi.check(self._lib.adsp_set_accumulate(self._h, 1 if on else 0))
+
+    def set_epilogue(self, effect=None):
+        """Fuse a stateless effect (effects.Effect) onto the kernel's output: later applies return effect(filter(x)).
+        None removes it.  float32 engines only."""
+        op, (p0, p1, p2) = (effect.op, effect.params()) if effect is not None else (_capi.EFFECT_NONE, (0.0, 0.0, 0.0))
+        _capi.check(self._lib.adsp_set_epilogue(self._h, int(op), float(p0), float(p1), float(p2)))
+        self.epilogue = effect
 
     def set_block_outputs(self, v):
         _capi.check(self._lib.adsp_set_block_outputs(self._h, int(v)))
@@ -161,6 +169,12 @@ class PartitionedFirEngine:
         self.channels, self.chunk_size, self.device = int(channels), int(fir.chunk_size), int(device)
         self.geometry = self.engines[0].geometry
         self.sample_format = "f32"
+        self.epilogue = None
+        self._lib = _capi.load()
+
+    def set_epilogue(self, effect=None):
+        """The partial sums must be complete before a non-linear effect: it runs as one extra in-place elementwise pass."""
+        self.epilogue = effect
 
     def close(self):
         for e in self.engines:
@@ -173,6 +187,11 @@ class PartitionedFirEngine:
     def apply_device(self, d_in, d_out, n_steps=1, stream=None):
         for e in self.engines:  # stream-ordered: part 0 overwrites, the others add
             e.apply_device(d_in, d_out, n_steps, stream)
+        if self.epilogue is not None:
+            p0, p1, p2 = (float(v) for v in self.epilogue.params())
+            n = int(n_steps) * self.channels * self.chunk_size
+            _capi.check(self._lib.adsp_effect_device(self.device, self.epilogue.op, p0, p1, p2, _ptr(d_out), _ptr(d_out), n,
+                                                     _ptr(stream)))
 
     def apply_host(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32)
@@ -184,7 +203,8 @@ class PartitionedFirEngine:
             acc = y if acc is None else acc + y
         for e in self.engines[1:]:
             e.set_accumulate(True)
-        return acc.astype(np.float32)
+        out = acc.astype(np.float32)
+        return out if self.epilogue is None else self.epilogue.apply(out, device=self.device)
 
     def synchronize(self, stream=None):
         self.engines[0].synchronize(stream)

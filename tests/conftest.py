@@ -36,4 +36,4 @@ def assert_parity(got, ref, rel=1e-5, what=""):
 
 @pytest.fixture(scope="session")
 def golden():
-    return {n: load_golden(n) for n in ("design", "kat_streams", "kat_chain", "kat_example1", "kat_edges")}
+    return {n: load_golden(n) for n in ("design", "kat_streams", "kat_chain", "kat_example1", "kat_edges", "kat_effects")}

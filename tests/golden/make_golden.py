@@ -181,6 +181,32 @@ def main():
     edge["highcut_listin"] = np.concatenate([dev.apply(list(x64[i * n:(i + 1) * n])) for i in range(4)])
     save("kat_edges", **edge)
 
+    # ---- H: stateless wave-shapers, alone and behind an FFT device ----------------
+    fx = {}
+    loud = (stream(100, 4096) * np.float32(1.5)).astype(np.float32)  # |x| up to 1.5: exercises every clipping branch
+    fx["softclip_044"] = ref.CreateSoftClipper().apply(loud)
+    fx["softclip_200"] = ref.CreateSoftClipper(2.0).apply(loud)
+    fx["harddist"] = ref.CreateHardDistortion().apply(loud)
+    fx["saturator_hard"] = ref.CreateSaturator().apply(loud)
+    fx["saturator_soft"] = ref.CreateSaturator(-12.0, 3.0, 'soft').apply(loud)
+    fx["volume_p6_clip"] = ref.VolumeChange(loud, 6.0)
+    fx["volume_m35_noclip"] = ref.VolumeChange(loud, -3.5, False)
+    ref.config.initialize(44100, 512)
+    x = stream(101, 8 * 512)
+    for tag, make in [("lowcut_softclip", lambda: (ref.CreateLowCutFilter(200), ref.CreateSoftClipper(0.44))),
+                      ("highcut_harddist", lambda: (ref.CreateHighCutFilter(8000), ref.CreateHardDistortion())),
+                      ("eq_saturator_soft", lambda: (ref.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5),
+                                                     ref.CreateSaturator(-12.0, 3.0, 'soft')))]:
+        dev, eff = make()
+        fx["chain512_" + tag] = np.concatenate([eff.apply(dev.apply(x[i * 512:(i + 1) * 512])) for i in range(8)])
+    ref.config.initialize(44100, 4096)
+    x = stream(102, 5 * 4096)
+    dev, eff = ref.CreateLowCutFilter(800), ref.CreateSaturator()
+    fx["chain4096_lowcut_saturator_hard"] = np.concatenate([eff.apply(dev.apply(x[i * 4096:(i + 1) * 4096])) for i in range(5)])
+    dev = ref.CreateEQ3BandFFT(100, 6, 700, 3, 8000, 6)  # boosts: output exceeds 1.0, the clip matters
+    fx["chain4096_eq_volume_p3"] = np.concatenate([ref.VolumeChange(dev.apply(x[i * 4096:(i + 1) * 4096]), 3.0) for i in range(5)])
+    save("kat_effects", **fx)
+
     with open(os.path.join(HERE, "META.txt"), "w") as fh:
         for k in sorted(meta):
             fh.write(f"{k} = {meta[k]}\n")
