@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--fft-mult", type=int, default=0, help="force transform length = this multiple of the chunk (0 = smallest)")
     ap.add_argument("--io", default="f32", choices=["f32", "s16"],
                     help="sample format of the resident batches: float32 (headline) or int16 PCM (fused WAV front end, 4 B/sample)")
+    ap.add_argument("--effect", default="none", choices=["none", "softclip", "harddist", "saturator", "volume", "tremolo"],
+                    help="fuse a stateless wave-shaper on the kernel's output (not part of the headline workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stream-extra", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -128,6 +130,12 @@ class Runner:
                                          sample_format=args.io, optimize_for="stream" if stream_mode else "batch")
         self.eng = eng = self.bank.engine
         assert eng.channels == C
+        if args.effect != "none":
+            from pyaudiodsptools_amd import config, effects
+            config.initialize(args.fs, N)  # the tremolo reads its sampling rate from the package config
+            eng.set_epilogue({"softclip": effects.CreateSoftClipper, "harddist": effects.CreateHardDistortion,
+                              "saturator": effects.CreateSaturator, "volume": lambda: effects.CreateVolumeChange(-3.0),
+                              "tremolo": effects.CreateTremolo}[args.effect]())
         self.stream = torch.cuda.current_stream(dev)
         sptr = self.stream.cuda_stream
         gen = torch.Generator(device=dev)
@@ -268,7 +276,7 @@ def main():
             "dtype": "f32" if args.io == "f32" else "f32 arithmetic on s16 samples",
             "data": ("synthetic uniform(-1,1) float32" if args.io == "f32" else "synthetic uniform int16 PCM (-6 dBFS)") + " resident in HBM " +
                     ("(library input ring)" if args.mode == "stream" else "([steps, channels, chunk] batches)"),
-            "config": {"workload": f"{FILTER_NAMES[args.filter]} @ {args.fs} Hz, {C} mono channels x {N}-sample chunks per GPU",
+            "config": {"workload": f"{FILTER_NAMES[args.filter]}{'' if args.effect == 'none' else ' -> ' + args.effect} @ {args.fs} Hz, {C} mono channels x {N}-sample chunks per GPU",
                        "channels_per_gpu": C, "chunk_size": N, "mode": mode_key, "steps_per_launch": main_run.spl,
                        "fft_size": eng.geometry.fft_size,
                        "outputs_per_transform": (N if args.mode == "stream" else eng.block_outputs),

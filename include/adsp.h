@@ -41,7 +41,7 @@ extern "C" {
 #define ADSP_API
 #endif
 
-#define ADSP_ABI_VERSION 2
+#define ADSP_ABI_VERSION 3
 #define ADSP_MAX_HISTORY 8
 
 typedef enum adsp_status {
@@ -129,23 +129,35 @@ ADSP_API int adsp_set_block_outputs(adsp_engine* engine, int block_outputs);
  *   VOLUME           Utility.py:171-194 VolumeChange          p0 = 10^(dB/20), p1 != 0 clips to [-1, 1]
  *   SOFT_CLIPPER     EffectSoftClipper.py:23-45               p0 = drive + 1
  *   HARD_DISTORTION  EffectHardDistortion.py:17-41            (no parameters)
- *   SATURATOR        EffectSaturator.py:16-49                 p0 = 10^(threshold_dB/20), p1 = 10^(makeup_dB/20), p2 = 1 hard / 2 soft */
+ *   SATURATOR        EffectSaturator.py:16-49                 p0 = 10^(threshold_dB/20), p1 = 10^(makeup_dB/20), p2 = 1 hard / 2 soft
+ *   TREMOLO          EffectTremolo.py:19-57                   p0 = depth, p1 = lfo_hz / sampling_rate, p2 = LFO table length
+ *                    (samples; the reference's len(arange(float32(fs / lfo)))).  Stateful only through the table index:
+ *                    a fused tremolo starts at index 0 when it is set and advances with every chunk the engine filters,
+ *                    following the reference's buffer arithmetic (EffectTremolo.py:40-45) including its replay quirk. */
 #define ADSP_EFFECT_NONE 0
 #define ADSP_EFFECT_VOLUME 1
 #define ADSP_EFFECT_SOFT_CLIPPER 2
 #define ADSP_EFFECT_HARD_DISTORTION 3
 #define ADSP_EFFECT_SATURATOR 4
+#define ADSP_EFFECT_TREMOLO 5
 /* every later apply of a float32 engine returns effect(filter(x)); ADSP_EFFECT_NONE removes it */
 ADSP_API int adsp_set_epilogue(adsp_engine* engine, int effect, float p0, float p1, float p2);
-/* out[i] = effect(in[i]) on device / host float32 arrays of n values (in-place allowed) */
-ADSP_API int adsp_effect_device(int device_id, int effect, float p0, float p1, float p2, const float* d_in, float* d_out,
-                                size_t n, void* stream);
-ADSP_API int adsp_effect_host(int device_id, int effect, float p0, float p1, float p2, const float* in, float* out, size_t n);
+/* out[i] = effect(in[i]) on device / host float32 arrays of n values (in-place allowed).  phase = LFO table index of
+ * element 0 (tremolo only, 0 <= phase < p2; ignored by the other effects) */
+ADSP_API int adsp_effect_device(int device_id, int effect, float p0, float p1, float p2, int phase, const float* d_in,
+                                float* d_out, size_t n, void* stream);
+ADSP_API int adsp_effect_host(int device_id, int effect, float p0, float p1, float p2, int phase, const float* in,
+                              float* out, size_t n);
+/* MixSignals (Utility.py:51-72): out[i] = sum_j inputs[j][i], clipped to [-1, 1] when clip != 0.  `inputs` is a HOST
+ * array of k device (adsp_mix_device) or host (adsp_mix_host) pointers; out may alias an input when k <= 8. */
+ADSP_API int adsp_mix_device(int device_id, const float* const* d_inputs, int k, int clip, float* d_out, size_t n, void* stream);
+ADSP_API int adsp_mix_host(int device_id, const float* const* inputs, int k, int clip, float* out, size_t n);
 
-/* Partitioned convolution: a kernel longer than one transform is split into parts, one engine per part (each with
- * the part's taps and delay); engines after the first ADD their partial result to the output buffer instead of
- * overwriting it.  Generic-geometry float32 engines only (adsp_apply_device / adsp_apply_ring outputs). */
-ADSP_API int adsp_set_accumulate(adsp_engine* engine, int accumulate);
+/* Output mode of a float32 engine.  0: overwrite the output buffer (default).  1: ADD the filtered samples to what
+ * the buffer holds - later parts of a partitioned convolution (a kernel longer than one transform is split into parts,
+ * one engine per part, each with the part's taps and delay), or several engines summing onto one mix bus.
+ * 2: add and clip the sum to [-1, 1] - the last engine of a MixSignals bus (Utility.py:51-72). */
+ADSP_API int adsp_set_accumulate(adsp_engine* engine, int mode);
 
 /* Forget all history (a fresh reference device). */
 ADSP_API int adsp_reset(adsp_engine* engine);

@@ -9,6 +9,8 @@ Reference anchors:
   * hard distortion   pyAudioDspTools/EffectHardDistortion.py:14-41
   * saturator         pyAudioDspTools/EffectSaturator.py:19-49
   * volume change     pyAudioDspTools/Utility.py:171-194
+  * tremolo           pyAudioDspTools/EffectTremolo.py:19-57
+  * mix               pyAudioDspTools/Utility.py:51-72
 """
 import numpy as np
 
@@ -47,3 +49,35 @@ def saturator(x, saturation_threshold_in_db=-20.0, makeup_gain=2.0, mode="hard")
 def volume_change(x, gain_change_in_db, overflow_protection=True):
     y = F(10 ** (gain_change_in_db / 20)) * np.asarray(x, F)
     return np.clip(y, F(-1), F(1)) if overflow_protection else y
+
+
+class OracleTremolo:
+    """The LFO table repeated end to end, consumed chunk by chunk; `buffered` is the length of the reference's
+    sin_lfo_copy, the whole state (the buffer always ends on a table end).  Keeps the reference's quirk: a buffer of
+    exactly one chunk is not consumed (``copy[-0:]``), so that chunk's table segment is replayed from then on."""
+
+    def __init__(self, sampling_rate, tremolo_depth=0.4, lfo_in_hertz=4.5):
+        n = np.arange(F(sampling_rate / lfo_in_hertz))  # float32 ramp, like the reference's
+        self.table = (((np.sin(2 * np.pi * lfo_in_hertz * n / sampling_rate) / 2) + 0.5) * tremolo_depth
+                      + (1 - tremolo_depth)).astype(F)
+        self.reset()
+
+    def reset(self):
+        self.buffered = len(self.table)
+
+    def apply(self, x):
+        x = np.asarray(x, F)
+        period = len(self.table)
+        while self.buffered < len(x):
+            self.buffered += period
+        idx = ((-self.buffered) % period + np.arange(len(x))) % period
+        if self.buffered != len(x):
+            self.buffered -= len(x)
+        return x * self.table[idx]
+
+
+def mix_signals(*signals):
+    acc = np.zeros(len(signals[0]))  # float64 accumulator, like the reference
+    for sig in signals:
+        acc = acc + sig
+    return np.clip(acc, -1.0, 1.0)

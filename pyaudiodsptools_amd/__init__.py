@@ -13,9 +13,9 @@ from . import config
 from .design import FirStream
 from .devices import (CreateEQ3BandFFT, CreateEQ3BandFFTGPU, CreateHighCutFilter, CreateHighCutFilterGPU,
                       CreateLowCutFilter, CreateLowCutFilterGPU, fuse)
-from .effects import (CreateHardDistortion, CreateSaturator, CreateSoftClipper, CreateVolumeChange, Effect,
-                      VolumeChange)
-from .engine import FirEngine, PartitionedFirEngine, make_engine
+from .effects import (CreateHardDistortion, CreateSaturator, CreateSoftClipper, CreateTremolo, CreateVolumeChange,
+                      Effect, MixSignals, VolumeChange)
+from .engine import FirEngine, MixBus, PartitionedFirEngine, make_engine
 from . import wavio as Utility
 from .wavio import (CombineChunks, MakeChunks, MonoWavToNumpy16BitInt, MonoWavToNumpyFloat, NumpyFloatToWav,
                     StereoWavToNumpyFloat, WavBank)
@@ -24,5 +24,5 @@ __all__ = ["config", "CreateHighCutFilter", "CreateLowCutFilter", "CreateEQ3Band
            "CreateLowCutFilterGPU", "CreateEQ3BandFFTGPU", "FirEngine", "PartitionedFirEngine", "make_engine", "FirStream", "fuse", "Utility", "MakeChunks",
            "CombineChunks", "MonoWavToNumpyFloat", "MonoWavToNumpy16BitInt", "StereoWavToNumpyFloat", "NumpyFloatToWav",
            "WavBank", "CreateSoftClipper", "CreateHardDistortion", "CreateSaturator", "VolumeChange", "CreateVolumeChange",
-           "Effect"]
+           "Effect", "CreateTremolo", "MixSignals", "MixBus"]
 __version__ = "0.1.0"

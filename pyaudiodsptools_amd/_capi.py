@@ -6,10 +6,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADSP_LIB") or os.path.join(_HERE, "libadsp.so")  # ADSP_LIB: tuning builds only
 
-ADSP_ABI_VERSION = 2
+ADSP_ABI_VERSION = 3
 ADSP_MAX_HISTORY = 8
 ADSP_FORMAT_F32, ADSP_FORMAT_S16 = 0, 1
-EFFECT_NONE, EFFECT_VOLUME, EFFECT_SOFT_CLIPPER, EFFECT_HARD_DISTORTION, EFFECT_SATURATOR = 0, 1, 2, 3, 4
+EFFECT_NONE, EFFECT_VOLUME, EFFECT_SOFT_CLIPPER, EFFECT_HARD_DISTORTION, EFFECT_SATURATOR, EFFECT_TREMOLO = 0, 1, 2, 3, 4, 5
 ADSP_OK, ADSP_ERR_ARG, ADSP_ERR_HIP, ADSP_ERR_STATE, ADSP_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 
 
@@ -51,9 +51,13 @@ SIGNATURES = {
     "adsp_set_block_outputs": (ctypes.c_int, [_engine_p, ctypes.c_int]),
     "adsp_set_epilogue": (ctypes.c_int, [_engine_p, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float]),
     "adsp_effect_device": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float,
-                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+                                          ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "adsp_effect_host": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float,
-                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+                                        ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "adsp_mix_device": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "adsp_mix_host": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_void_p, ctypes.c_size_t]),
     "adsp_set_accumulate": (ctypes.c_int, [_engine_p, ctypes.c_int]),
     "adsp_reset": (ctypes.c_int, [_engine_p]),
     "adsp_apply_host": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),

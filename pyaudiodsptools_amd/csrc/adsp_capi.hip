@@ -16,12 +16,38 @@
 #include "../../include/adsp.h"
 #include "plan_table.hpp"
 
-// standalone elementwise form of the fused output effects (fftconv_kernel.hpp::epilogue_value): out[i] = effect(in[i])
+// standalone elementwise form of the fused output effects (fftconv_kernel.hpp::epilogue_value): out[i] = effect(in[i]);
+// the tremolo multiplies by its periodic LFO table, element 0 at table index `phase`
 __global__ void adsp_pointwise_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n, int op, float p0,
-                                      float p1, float p2) {
+                                      float p1, float p2, int phase) {
     const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
-    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
-        out[i] = adsp::epilogue_value(in[i], op, p0, p1, p2);
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (op == ADSP_EFFECT_TREMOLO) {
+            const unsigned len = static_cast<unsigned>(p2);
+            const int idx = static_cast<int>((static_cast<unsigned long long>(phase) + i) % len);
+            out[i] = in[i] * adsp::tremolo_gain(idx, p0, p1);
+        } else {
+            out[i] = adsp::epilogue_value(in[i], op, p0, p1, p2);
+        }
+    }
+}
+
+// MixSignals (Utility.py:51-72): out = clip(sum of k signals) - up to 8 addends per pass
+struct MixArgs {
+    const float* in[8];
+    int k;
+    int add_existing;  // out already holds a partial sum
+    int clip;
+};
+__global__ void adsp_mix_kernel(MixArgs a, float* __restrict__ out, size_t n) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float acc = a.add_existing ? out[i] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < a.k) acc += a.in[j][i];
+        out[i] = a.clip ? __builtin_amdgcn_fmed3f(acc, -1.f, 1.f) : acc;
+    }
 }
 
 namespace {
@@ -153,8 +179,13 @@ struct adsp_engine {
     const PlanInfo* plan;
     int M, logN, block_outputs;
     int epi_op;       // fused output effect (ADSP_EFFECT_*), 0 = none
+    int lfo_len;      // tremolo: LFO table length and the reference's buffer length (EffectTremolo.py:40-45)
+    long long lfo_copy_len;
+    int epi_phase;
+    const PlanInfo* plan_epi;  // twin of `plan` whose kernel applies the effect (nullptr: none available)
+    bool epi_prepared;
     float epi_p[3];
-    bool accumulate;  // add to the output instead of overwriting (generic float engines; partitioned FIRs)
+    int accumulate;   // 0 overwrite the output, 1 add to it (partitioned FIRs, mix bus), 2 add and clip to [-1, 1]
     bool generic;  // generic-geometry kernel (chunk not a power of two / F not 2N or 4N)
     char* ring;    // [ring_slots][C][N] samples of cfg.sample_format
     int ring_pos;  // slot of the most recent chunk
@@ -227,7 +258,9 @@ int upload_pairs(adsp_engine* e, const float* H, hipStream_t stream) {
 
 int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream_t stream) {
     const adsp_config& c = e->cfg;
-    const PlanInfo& pl = *e->plan;
+    // same transform; the twin kernel has the output effect / mix bus compiled in (the plain generic kernel can add)
+    const bool twin = e->epi_op != 0 || e->accumulate == 2 || (e->accumulate == 1 && !e->generic);
+    const PlanInfo& pl = twin ? *e->plan_epi : *e->plan;
     adsp::KernelArgs a;
     a.ring = e->ring;
     a.in = d_in;
@@ -244,7 +277,8 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
     a.N = c.chunk_size;
     a.nh = c.history_chunks;
     a.inv_n = 1.0f / (float)c.chunk_size;
-    a.accumulate = e->accumulate ? 1 : 0;
+    a.accumulate = e->accumulate;
+    a.epi_phase = e->epi_phase;
     a.epi_op = e->epi_op;
     a.epi_p0 = e->epi_p[0];
     a.epi_p1 = e->epi_p[1];
@@ -357,8 +391,19 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     e->M = F / 2;
     e->logN = ilog2(N);
     e->generic = generic;
-    e->accumulate = false;
+    e->accumulate = 0;
     e->epi_op = 0;
+    e->lfo_len = 0;
+    e->lfo_copy_len = 0;
+    e->epi_phase = 0;
+    e->plan_epi = nullptr;
+    e->epi_prepared = false;
+    if (e->cfg.sample_format == ADSP_FORMAT_F32) {
+        int n = 0, ne = 0;
+        const PlanInfo* tab = adsp::plans_f32(&n);
+        const PlanInfo* tab_epi = adsp::plans_f32_epi(&ne);
+        if (pl >= tab && pl < tab + n && ne == n) e->plan_epi = &tab_epi[pl - tab];
+    }
     e->epi_p[0] = e->epi_p[1] = e->epi_p[2] = 0.f;
     // samples kept per transform: one chunk for the specialised kernels' single-step launches; the generic kernel
     // always tiles the time axis with block_outputs (default: as many whole segments as the transform offers)
@@ -462,39 +507,134 @@ int adsp_set_block_outputs(adsp_engine* e, int v) {
     return ADSP_OK;
 }
 
+namespace {
+int prepare_twin(adsp_engine* e) {
+    if (!e->plan_epi) return fail(ADSP_ERR_STATE, "no effect kernel for this (tuning) plan");
+    if (!e->epi_prepared) {
+        int rc = set_device(e);
+        if (rc) return rc;
+        HIP_TRY(e->generic ? e->plan_epi->prepare_generic() : e->plan_epi->prepare());
+        e->epi_prepared = true;
+    }
+    return ADSP_OK;
+}
+
+// The reference's tremolo keeps a buffer of LFO tables and cuts each chunk off its front (EffectTremolo.py:40-45).
+// Its length is the whole state: the buffer always ends on a table end, so the next chunk starts at table index
+// (-length) mod table.  One quirk is kept: when the buffer holds EXACTLY one chunk, `copy[-0:]` keeps all of it, and
+// every later chunk replays that same segment.  Returns how many of the next max_steps chunks run on contiguously.
+int tremolo_run(adsp_engine* e, int max_steps, int* phase) {
+    const long long N = e->cfg.chunk_size, L = e->lfo_len;
+    long long len = e->lfo_copy_len;
+    while (len < N) len += L;
+    *phase = (int)((L - len % L) % L);
+    int run = 0;
+    while (run < max_steps) {
+        while (len < N) len += L;
+        ++run;
+        if (len == N) break;  // replayed from now on: the next run starts at the same table index again
+        len -= N;
+    }
+    e->lfo_copy_len = len;
+    return run;
+}
+}  // namespace
+
 int adsp_set_epilogue(adsp_engine* e, int effect, float p0, float p1, float p2) {
     if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
-    if (effect < ADSP_EFFECT_NONE || effect > ADSP_EFFECT_SATURATOR) return fail(ADSP_ERR_ARG, "unknown effect %d", effect);
+    if (effect < ADSP_EFFECT_NONE || effect > ADSP_EFFECT_TREMOLO) return fail(ADSP_ERR_ARG, "unknown effect %d", effect);
     if (effect != ADSP_EFFECT_NONE && e->cfg.sample_format != ADSP_FORMAT_F32)
         return fail(ADSP_ERR_ARG, "fused effects need a float32 engine");
+    if (effect == ADSP_EFFECT_TREMOLO && !(p2 >= 1.f && p2 <= 8388608.f && p2 == (float)(int)p2))
+        return fail(ADSP_ERR_ARG, "tremolo: p2 must be the LFO table length, an integer in 1..2^23");
+    if (effect != ADSP_EFFECT_NONE) {
+        int rc = prepare_twin(e);
+        if (rc) return rc;
+    }
     e->epi_op = effect;
     e->epi_p[0] = p0;
     e->epi_p[1] = p1;
     e->epi_p[2] = p2;
+    e->lfo_len = effect == ADSP_EFFECT_TREMOLO ? (int)p2 : 0;
+    e->lfo_copy_len = e->lfo_len;  // a fresh LFO: one table in the buffer (EffectTremolo.py:24)
+    e->epi_phase = 0;
     return ADSP_OK;
 }
 
 namespace {
-int pointwise_launch(int device_id, int effect, float p0, float p1, float p2, const float* d_in, float* d_out, size_t n,
-                     hipStream_t stream) {
-    if (effect < ADSP_EFFECT_NONE || effect > ADSP_EFFECT_SATURATOR) return fail(ADSP_ERR_ARG, "unknown effect %d", effect);
+int pointwise_launch(int device_id, int effect, float p0, float p1, float p2, int phase, const float* d_in, float* d_out,
+                     size_t n, hipStream_t stream) {
+    if (effect < ADSP_EFFECT_NONE || effect > ADSP_EFFECT_TREMOLO) return fail(ADSP_ERR_ARG, "unknown effect %d", effect);
+    if (effect == ADSP_EFFECT_TREMOLO && (!(p2 >= 1.f && p2 <= 8388608.f) || phase < 0 || phase >= (int)p2))
+        return fail(ADSP_ERR_ARG, "tremolo: p2 = table length (1..2^23), 0 <= phase < p2");
     HIP_TRY(hipSetDevice(device_id));
     if (n == 0) return ADSP_OK;
     size_t blocks = (n + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;  // grid-stride beyond 8 workgroups per CU
-    hipLaunchKernelGGL(adsp_pointwise_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_in, d_out, n, effect, p0, p1, p2);
+    hipLaunchKernelGGL(adsp_pointwise_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_in, d_out, n, effect, p0, p1, p2, phase);
     HIP_TRY(hipGetLastError());
     return ADSP_OK;
 }
 }  // namespace
 
-int adsp_effect_device(int device_id, int effect, float p0, float p1, float p2, const float* d_in, float* d_out,
-                       size_t n, void* stream) {
+int adsp_effect_device(int device_id, int effect, float p0, float p1, float p2, int phase, const float* d_in,
+                       float* d_out, size_t n, void* stream) {
     if (!d_in || !d_out) return fail(ADSP_ERR_ARG, "NULL argument");
-    return pointwise_launch(device_id, effect, p0, p1, p2, d_in, d_out, n, (hipStream_t)stream);
+    return pointwise_launch(device_id, effect, p0, p1, p2, phase, d_in, d_out, n, (hipStream_t)stream);
 }
 
-int adsp_effect_host(int device_id, int effect, float p0, float p1, float p2, const float* in, float* out, size_t n) {
+int adsp_mix_device(int device_id, const float* const* d_inputs, int k, int clip, float* d_out, size_t n, void* stream) {
+    if (!d_inputs || !d_out) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (k < 1) return fail(ADSP_ERR_ARG, "mix needs at least one input");
+    for (int j = 0; j < k; ++j)
+        if (!d_inputs[j]) return fail(ADSP_ERR_ARG, "NULL input %d", j);
+    HIP_TRY(hipSetDevice(device_id));
+    if (n == 0) return ADSP_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    for (int j0 = 0; j0 < k; j0 += 8) {
+        MixArgs a;
+        a.k = k - j0 < 8 ? k - j0 : 8;
+        for (int j = 0; j < 8; ++j) a.in[j] = j < a.k ? d_inputs[j0 + j] : nullptr;
+        a.add_existing = j0 > 0;
+        a.clip = (clip && j0 + 8 >= k) ? 1 : 0;
+        hipLaunchKernelGGL(adsp_mix_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, d_out, n);
+        HIP_TRY(hipGetLastError());
+    }
+    return ADSP_OK;
+}
+
+int adsp_mix_host(int device_id, const float* const* inputs, int k, int clip, float* out, size_t n) {
+    if (!inputs || !out) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (k < 1) return fail(ADSP_ERR_ARG, "mix needs at least one input");
+    for (int j = 0; j < k; ++j)
+        if (!inputs[j]) return fail(ADSP_ERR_ARG, "NULL input %d", j);
+    int ndev = 0;
+    int rc = adsp_device_count(&ndev);
+    if (rc) return rc;
+    if (device_id < 0 || device_id >= ndev) return fail(ADSP_ERR_ARG, "device_id %d out of range (%d devices)", device_id, ndev);
+    HIP_TRY(hipSetDevice(device_id));
+    if (n == 0) return ADSP_OK;
+    float* d = nullptr;  // [k + 1][n]: the inputs, then the sum
+    HIP_TRY(hipMalloc(&d, (size_t)(k + 1) * n * sizeof(float)));
+    std::vector<const float*> ptrs(k);
+    hipError_t err = hipSuccess;
+    for (int j = 0; j < k && err == hipSuccess; ++j) {
+        ptrs[j] = d + (size_t)j * n;
+        err = hipMemcpy(d + (size_t)j * n, inputs[j], n * sizeof(float), hipMemcpyHostToDevice);
+    }
+    if (err == hipSuccess) {
+        rc = adsp_mix_device(device_id, ptrs.data(), k, clip, d + (size_t)k * n, n, nullptr);
+        if (rc == ADSP_OK) err = hipMemcpy(out, d + (size_t)k * n, n * sizeof(float), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d);
+    if (rc) return rc;
+    if (err != hipSuccess) return fail(ADSP_ERR_HIP, "mix copy failed: %s", hipGetErrorString(err));
+    return ADSP_OK;
+}
+
+int adsp_effect_host(int device_id, int effect, float p0, float p1, float p2, int phase, const float* in, float* out,
+                     size_t n) {
     if (!in || !out) return fail(ADSP_ERR_ARG, "NULL argument");
     int ndev = 0;
     int rc = adsp_device_count(&ndev);
@@ -506,7 +646,7 @@ int adsp_effect_host(int device_id, int effect, float p0, float p1, float p2, co
     HIP_TRY(hipMalloc(&d, n * sizeof(float)));
     hipError_t err = hipMemcpy(d, in, n * sizeof(float), hipMemcpyHostToDevice);
     if (err == hipSuccess) {
-        rc = pointwise_launch(device_id, effect, p0, p1, p2, d, d, n, nullptr);
+        rc = pointwise_launch(device_id, effect, p0, p1, p2, phase, d, d, n, nullptr);
         if (rc == ADSP_OK) err = hipMemcpy(out, d, n * sizeof(float), hipMemcpyDeviceToHost);
     }
     (void)hipFree(d);
@@ -515,11 +655,15 @@ int adsp_effect_host(int device_id, int effect, float p0, float p1, float p2, co
     return ADSP_OK;
 }
 
-int adsp_set_accumulate(adsp_engine* e, int on) {
+int adsp_set_accumulate(adsp_engine* e, int mode) {
     if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
-    if (on && (!e->generic || e->cfg.sample_format != ADSP_FORMAT_F32))
-        return fail(ADSP_ERR_ARG, "accumulating output needs a generic-geometry float32 engine");
-    e->accumulate = on != 0;
+    if (mode < 0 || mode > 2) return fail(ADSP_ERR_ARG, "accumulate mode must be 0, 1 or 2");
+    if (mode && e->cfg.sample_format != ADSP_FORMAT_F32) return fail(ADSP_ERR_ARG, "accumulating output needs a float32 engine");
+    if (mode == 2 || (mode == 1 && !e->generic)) {  // these run on the twin kernel
+        int rc = prepare_twin(e);
+        if (rc) return rc;
+    }
+    e->accumulate = mode;
     return ADSP_OK;
 }
 
@@ -534,12 +678,32 @@ int adsp_reset(adsp_engine* e) {
     return ADSP_OK;
 }
 
+namespace {
+int apply_device_run(adsp_engine* e, const void* d_in, void* d_out, int n_steps, void* stream_v);
+}
+
 int adsp_apply_device(adsp_engine* e, const void* d_in, void* d_out, int n_steps, void* stream_v) {
     if (!e || !d_in || !d_out) return fail(ADSP_ERR_ARG, "NULL argument");
     if (n_steps <= 0) return fail(ADSP_ERR_ARG, "n_steps must be positive");
     if (!e->have_spectrum) return fail(ADSP_ERR_STATE, "adsp_set_spectrum has not been called");
     int rc = set_device(e);
     if (rc) return rc;
+    if (e->epi_op != ADSP_EFFECT_TREMOLO) return apply_device_run(e, d_in, d_out, n_steps, stream_v);
+    // the LFO runs on contiguously except where the reference's buffer quirk restarts it: one launch per run
+    const size_t plane = e->plane_bytes();
+    for (int done = 0; done < n_steps;) {
+        const int run = tremolo_run(e, n_steps - done, &e->epi_phase);
+        rc = apply_device_run(e, static_cast<const char*>(d_in) + (size_t)done * plane, static_cast<char*>(d_out) + (size_t)done * plane,
+                              run, stream_v);
+        if (rc) return rc;
+        done += run;
+    }
+    return ADSP_OK;
+}
+
+namespace {
+int apply_device_run(adsp_engine* e, const void* d_in, void* d_out, int n_steps, void* stream_v) {
+    int rc;
     hipStream_t stream = (hipStream_t)stream_v;
     const int S = e->cfg.ring_slots;
     const int cnt = n_steps < e->cfg.history_chunks ? n_steps : e->cfg.history_chunks;
@@ -571,6 +735,7 @@ int adsp_apply_device(adsp_engine* e, const void* d_in, void* d_out, int n_steps
     e->ring_pos = (e->ring_pos + cnt) % S;
     return ADSP_OK;
 }
+}  // namespace
 
 int adsp_ring_acquire(adsp_engine* e, void** d_slot) {
     if (!e || !d_slot) return fail(ADSP_ERR_ARG, "NULL argument");
@@ -589,6 +754,7 @@ int adsp_apply_ring(adsp_engine* e, void* d_out, void* stream_v) {
         e->copy_pending = false;
     }
     const int slot = (e->ring_pos + 1) % e->cfg.ring_slots;
+    if (e->epi_op == ADSP_EFFECT_TREMOLO) (void)tremolo_run(e, 1, &e->epi_phase);
     if ((rc = launch(e, e->ring + (size_t)slot * e->plane_bytes(), d_out, 1, (hipStream_t)stream_v))) return rc;
     e->ring_pos = slot;
     return ADSP_OK;

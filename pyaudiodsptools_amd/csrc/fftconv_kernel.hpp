@@ -82,7 +82,9 @@ struct KernelArgs {
     float inv_n;           // 1 / N
     int epi_op;            // fused output epilogue (0 = none), see apply_epilogue
     float epi_p0, epi_p1, epi_p2;
-    int accumulate;        // generic float kernel: add the kept samples to `out` instead of overwriting (partitioned FIRs)
+    int epi_phase;         // tremolo: LFO table index of this launch's output sample 0
+    int accumulate;        // 1: add the kept samples to what `out` holds (partitioned FIRs, mixing); 2: and clip the sum
+                           // to [-1, 1] (MixSignals).  Plain kernels: generic geometry + mode 1 only; EPI kernels: all.
 };
 
 // ------------------------------------------------------------------------------------------
@@ -604,9 +606,9 @@ __device__ __forceinline__ void load_window(const float* const (&cb)[FN + 1], fl
     }
 }
 
-template <class PL, int FN, int RQ>
+template <class PL, int FN, int RQ, bool EPI = false>
 __device__ __forceinline__ void store_kept(float* const (&ob)[FN + 1], const float (&xr)[PL::P],
-                                           const float (&xi)[PL::P], int m_lo, int m_hi, bool odd) {
+                                           const float (&xi)[PL::P], int m_lo, int m_hi, bool odd, int mix = 0) {
     constexpr int P = PL::P, T = PL::T, MPC = P / FN, Q = MPC / 4;
     if constexpr (ADSP_WIDE_IO && Q % 2 == 0) {
 #pragma unroll
@@ -618,8 +620,17 @@ __device__ __forceinline__ void store_kept(float* const (&ob)[FN + 1], const flo
                 // even lane stores (own, neighbour's) of register 2u; odd lane (neighbour's, own) of register 2u+1
                 const float sx = lane_xor1(odd ? xr[2 * u] : xr[2 * u + 1]);
                 const float sy = lane_xor1(odd ? xi[2 * u] : xi[2 * u + 1]);
-                const float4 v = odd ? make_float4(sx, sy, xr[2 * u + 1], xi[2 * u + 1])
-                                     : make_float4(xr[2 * u], xi[2 * u], sx, sy);
+                float4 v = odd ? make_float4(sx, sy, xr[2 * u + 1], xi[2 * u + 1])
+                               : make_float4(xr[2 * u], xi[2 * u], sx, sy);
+                if constexpr (EPI) {
+                    if (mix) {  // wave-uniform: add what the output already holds (MixSignals: and clip)
+                        const float4 old = *reinterpret_cast<const float4*>(ob[i] + off);
+                        v = make_float4(v.x + old.x, v.y + old.y, v.z + old.z, v.w + old.w);
+                        if (mix == 2)
+                            v = make_float4(__builtin_amdgcn_fmed3f(v.x, -1.f, 1.f), __builtin_amdgcn_fmed3f(v.y, -1.f, 1.f),
+                                            __builtin_amdgcn_fmed3f(v.z, -1.f, 1.f), __builtin_amdgcn_fmed3f(v.w, -1.f, 1.f));
+                    }
+                }
 #if ADSP_ABLATE & 16
                 if (xr[2 * u] == 123.456f) *reinterpret_cast<float4*>(ob[i] + off) = v;
 #elif ADSP_NT & 1
@@ -638,10 +649,18 @@ __device__ __forceinline__ void store_kept(float* const (&ob)[FN + 1], const flo
                 const int gi = RQ * Q + m;
                 const int i = gi / MPC;
                 const int off = (gi % MPC) * 2 * T;
+                float2 v = make_float2(xr[m], xi[m]);
+                if constexpr (EPI) {
+                    if (mix) {
+                        const float2 old = *reinterpret_cast<const float2*>(ob[i] + off);
+                        v = make_float2(v.x + old.x, v.y + old.y);
+                        if (mix == 2) v = make_float2(__builtin_amdgcn_fmed3f(v.x, -1.f, 1.f), __builtin_amdgcn_fmed3f(v.y, -1.f, 1.f));
+                    }
+                }
 #if ADSP_ABLATE & 16
-                if (xr[m] == 123.456f) *reinterpret_cast<float2*>(ob[i] + off) = make_float2(xr[m], xi[m]);
+                if (xr[m] == 123.456f) *reinterpret_cast<float2*>(ob[i] + off) = v;
 #else
-                *reinterpret_cast<float2*>(ob[i] + off) = make_float2(xr[m], xi[m]);
+                *reinterpret_cast<float2*>(ob[i] + off) = v;
 #endif
             }
         }
@@ -733,47 +752,97 @@ __device__ __forceinline__ void store_kept_s16(unsigned* const (&ob)[FN + 1], co
 //   3 CreateHardDistortion EffectHardDistortion.py:30-41  (0.8 + 0.2 sin((a - 0.8)/0.2)) sgn, with a = |x| if |x| <= 0.8
 //                       else sgn(x) (so x < -0.8 lands on sin(-9): the reference's asymmetry is kept)
 //   4 CreateSaturator   EffectSaturator.py:41-49    knee above p0, (p0+1)/2 above 1, makeup p1, mode p2 (1 hard, 2 soft)
+//   5 CreateTremolo     EffectTremolo.py:19-47      periodic LFO table of p2 samples: gain = 1 - p0/2 + p0/2 sin(2 pi p1 n)
 // ------------------------------------------------------------------------------------------
+// One sample through effect OP (compile-time) - the reference's expressions in float32, with hardware log2/exp2/sin/rcp
+// (each ~1 ulp; the parity tolerance is 1e-5 of full scale).
+template <int OP>
+__device__ __forceinline__ float effect_sample(float x, float p0, float p1, float p2) {
+    if constexpr (OP == 1) {  // volume: p0 = linear gain, p1 = clip flag
+        const float y = p0 * x;
+        return p1 != 0.f ? __builtin_amdgcn_fmed3f(y, -1.f, 1.f) : y;
+    } else if constexpr (OP == 2) {  // soft clipper: sign(x) (1 - |min(|x|,1) - 1|^p0), p0 = drive + 1
+        const float a = fminf(fabsf(x), 1.f);
+        const float t = 1.f - __builtin_amdgcn_exp2f(p0 * __builtin_amdgcn_logf(1.f - a));  // log2(0) = -inf -> 0
+        return __builtin_copysignf(t, x);
+    } else if constexpr (OP == 3) {  // hard distortion (0.8 linear limit; beyond it the SIGN is the amplitude)
+        const float sgn = x >= 0.f ? 1.f : -1.f;
+        float a = fabsf(x);
+        a = a <= 0.8f ? a : sgn;
+        // v_sin_f32 takes revolutions: (a - 0.8) / 0.2 rad = (a - 0.8) * 5 / (2 pi) rev, |arg| < 1.5 rev
+        const float comp = 0.2f * __builtin_amdgcn_sinf((a - 0.8f) * 0.795774715459f);
+        return (0.8f + comp) * sgn;
+    } else if constexpr (OP == 4) {  // saturator: p0 = threshold, p1 = linear make-up gain, p2 = 1 hard / 2 soft
+        float a = fabsf(x);
+        const float u = a - p0;
+        float r = u * __builtin_amdgcn_rcpf(1.f - p0);
+        r = p2 == 2.f ? r * r : r;
+        const float knee = p0 + u * __builtin_amdgcn_rcpf(1.f + r);
+        a = a > p0 ? knee : a;
+        a = a > 1.f ? (p0 + 1.f) * 0.5f : a;
+        return __builtin_copysignf(a, x) * p1;
+    } else {
+        return x;
+    }
+}
+
+// Tremolo gain of LFO table index n (EffectTremolo.py:20-23): ((sin(2 pi f n / fs) / 2) + 0.5) depth + (1 - depth)
+__device__ __forceinline__ float tremolo_gain(int n, float depth, float rev_per_sample) {
+    return fmaf(0.5f * depth, __builtin_amdgcn_sinf(static_cast<float>(n) * rev_per_sample), 1.f - 0.5f * depth);
+}
+// n mod len for 0 <= n < 2^24 (float reciprocal, one correction either way)
+__device__ __forceinline__ int small_mod(int n, int len, float inv_len) {
+    int r = n - static_cast<int>(static_cast<float>(n) * inv_len) * len;
+    r += r < 0 ? len : 0;
+    r -= r >= len ? len : 0;
+    return r;
+}
+
 __device__ __forceinline__ float epilogue_value(float x, int op, float p0, float p1, float p2) {
     switch (op) {
-        case 1: {
-            float y = p0 * x;
-            return p1 != 0.f ? fminf(fmaxf(y, -1.f), 1.f) : y;
-        }
-        case 2: {
-            const float a = fminf(fabsf(x), 1.f);
-            const float t = 1.f - __powf(fabsf(a - 1.f), p0);
-            return x < 0.f ? -t : t;
-        }
-        case 3: {
-            const float sgn = x >= 0.f ? 1.f : -1.f;
-            float a = fabsf(x);
-            a = a <= 0.8f ? a : sgn;
-            const float comp = 0.2f * __sinf((a - 0.8f) / 0.2f);
-            return (0.8f + comp) * sgn;
-        }
-        case 4: {
-            float a = fabsf(x);
-            if (a > p0) {
-                const float u = a - p0;
-                float r = u / (1.f - p0);
-                r = p2 == 2.f ? r * r : r;
-                a = p0 + u / (1.f + r);
-            }
-            if (a > 1.f) a = (p0 + 1.f) * 0.5f;
-            return (x < 0.f ? -a : a) * p1;
-        }
+        case 1: return effect_sample<1>(x, p0, p1, p2);
+        case 2: return effect_sample<2>(x, p0, p1, p2);
+        case 3: return effect_sample<3>(x, p0, p1, p2);
+        case 4: return effect_sample<4>(x, p0, p1, p2);
         default: return x;
     }
 }
 
-template <int P>
-__device__ __forceinline__ void apply_epilogue(float (&xr)[P], float (&xi)[P], const KernelArgs& a) {
-    if (a.epi_op == 0) return;  // wave-uniform
+template <int OP, int P>
+__device__ __forceinline__ void epilogue_loop(float (&xr)[P], float (&xi)[P], const KernelArgs& a) {
 #pragma unroll
     for (int m = 0; m < P; ++m) {
-        xr[m] = epilogue_value(xr[m], a.epi_op, a.epi_p0, a.epi_p1, a.epi_p2);
-        xi[m] = epilogue_value(xi[m], a.epi_op, a.epi_p0, a.epi_p1, a.epi_p2);
+        xr[m] = effect_sample<OP>(xr[m], a.epi_p0, a.epi_p1, a.epi_p2);
+        xi[m] = effect_sample<OP>(xi[m], a.epi_p0, a.epi_p1, a.epi_p2);
+    }
+}
+
+// Tremolo: the reference multiplies the stream by a periodic table of len = p2 samples (EffectTremolo.py:20-47);
+// register m of thread tid holds output times tau0 + 2 T m (+1 for the imaginary part), tau0 = block start - j0 + 2 tid.
+template <int P, int T>
+__device__ __forceinline__ void tremolo_loop(float (&xr)[P], float (&xi)[P], const KernelArgs& a, int tau0) {
+    const int len = static_cast<int>(a.epi_p2);
+    const float inv_len = 1.f / a.epi_p2;
+    int base = (a.epi_phase + tau0) % len;  // once per thread; tau0 may be negative for samples that are not kept
+    base += base < 0 ? len : 0;
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+        const int n = small_mod(base + 2 * T * m, len, inv_len);
+        const int n1 = n + 1 == len ? 0 : n + 1;
+        xr[m] *= tremolo_gain(n, a.epi_p0, a.epi_p1);
+        xi[m] *= tremolo_gain(n1, a.epi_p0, a.epi_p1);
+    }
+}
+
+template <int P, int T>
+__device__ __forceinline__ void apply_epilogue(float (&xr)[P], float (&xi)[P], const KernelArgs& a, int tau0) {
+    switch (a.epi_op) {  // wave-uniform
+        case 0: return;
+        case 5: return tremolo_loop<P, T>(xr, xi, a, tau0);
+        case 1: return epilogue_loop<1>(xr, xi, a);
+        case 2: return epilogue_loop<2>(xr, xi, a);
+        case 3: return epilogue_loop<3>(xr, xi, a);
+        case 4: return epilogue_loop<4>(xr, xi, a);
     }
 }
 
@@ -808,7 +877,7 @@ __device__ __forceinline__ void transform_block(float (&xr)[PL::P], float (&xi)[
 // ------------------------------------------------------------------------------------------
 // the kernel: one workgroup = CPB channels x one time block
 // ------------------------------------------------------------------------------------------
-template <class PL, int CPB, int FN, bool S16 = false>
+template <class PL, int CPB, int FN, bool S16 = false, bool EPI = false>
 __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(const KernelArgs a) {
     constexpr int M = PL::M, P = PL::P, T = PL::T;
     constexpr int N = 2 * M / FN;  // chunk size
@@ -888,7 +957,7 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(con
     }
 
     transform_block<PL>(xr, xi, lds, a, tid);
-    if constexpr (!S16) apply_epilogue<P>(xr, xi, a);
+    if constexpr (EPI) apply_epilogue<P, T>(xr, xi, a, blk * a.V - a.j0 + 2 * tid);  // separate instantiation: the plain kernel pays nothing
 
     // kept samples: circular indices [j0, j0 + keep) -> registers m_lo <= m < m_hi; register m holds
     // output-time o - j0 + 2T*m.  s = o - j0 may be negative: split into chunk part and phase.
@@ -914,10 +983,10 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(con
             }
         } else {
             switch ((s & (N - 1)) >> (LOGN - 2)) {
-                case 0: store_kept<PL, FN, 0>(ob, xr, xi, m_lo, m_hi, odd); break;
-                case 1: store_kept<PL, FN, 1>(ob, xr, xi, m_lo, m_hi, odd); break;
-                case 2: store_kept<PL, FN, 2>(ob, xr, xi, m_lo, m_hi, odd); break;
-                default: store_kept<PL, FN, 3>(ob, xr, xi, m_lo, m_hi, odd); break;
+                case 0: store_kept<PL, FN, 0, EPI>(ob, xr, xi, m_lo, m_hi, odd, a.accumulate); break;
+                case 1: store_kept<PL, FN, 1, EPI>(ob, xr, xi, m_lo, m_hi, odd, a.accumulate); break;
+                case 2: store_kept<PL, FN, 2, EPI>(ob, xr, xi, m_lo, m_hi, odd, a.accumulate); break;
+                default: store_kept<PL, FN, 3, EPI>(ob, xr, xi, m_lo, m_hi, odd, a.accumulate); break;
             }
         }
     }
@@ -941,7 +1010,7 @@ __device__ __forceinline__ void locate_chunk(int tau_biased, int N, float inv_n,
     }
 }
 
-template <class PL, int CPB, bool S16 = false>
+template <class PL, int CPB, bool S16 = false, bool EPI = false>
 __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_generic_kernel(const KernelArgs a) {
     constexpr int M = PL::M, P = PL::P, T = PL::T;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1005,7 +1074,7 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_generic_ke
     }
 
     transform_block<PL>(xr, xi, lds, a, tid);
-    if constexpr (!S16) apply_epilogue<P>(xr, xi, a);
+    if constexpr (EPI) apply_epilogue<P, T>(xr, xi, a, blk * a.V - a.j0 + 2 * tid);  // separate instantiation: the plain kernel pays nothing
 
     const long long total_ll = static_cast<long long>(a.n_steps) * N;
     const int total = static_cast<int>(total_ll);
@@ -1036,7 +1105,12 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_generic_ke
                 } else {
                     typedef float v4f __attribute__((ext_vector_type(4)));
                     v4f v = odd ? v4f{sx, sy, xr[2 * u + 1], xi[2 * u + 1]} : v4f{xr[2 * u], xi[2 * u], sx, sy};
-                    if (a.accumulate) v += *reinterpret_cast<const v4f*>(dst);  // partial sum of an earlier partition
+                    if (a.accumulate) v += *reinterpret_cast<const v4f*>(dst);  // partial sum of an earlier partition / mix bus
+                    if constexpr (EPI) {
+                        if (a.accumulate == 2)
+                            v = v4f{__builtin_amdgcn_fmed3f(v.x, -1.f, 1.f), __builtin_amdgcn_fmed3f(v.y, -1.f, 1.f),
+                                    __builtin_amdgcn_fmed3f(v.z, -1.f, 1.f), __builtin_amdgcn_fmed3f(v.w, -1.f, 1.f)};
+                    }
                     __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(dst));
                 }
             }

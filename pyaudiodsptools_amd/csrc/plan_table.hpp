@@ -19,61 +19,62 @@ struct PlanInfo {
     hipError_t (*prepare_generic)();
 };
 
-template <class PL, int CPB, int FN, bool S16>
+template <class PL, int CPB, int FN, bool S16, bool EPI>
 hipError_t launch_impl(const KernelArgs& a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((fftconv_kernel<PL, CPB, FN, S16>), dim3(grid), dim3(PL::T * CPB), PL::M * CPB * sizeof(float2), s, a);
+    hipLaunchKernelGGL((fftconv_kernel<PL, CPB, FN, S16, EPI>), dim3(grid), dim3(PL::T * CPB), PL::M * CPB * sizeof(float2), s, a);
     return hipGetLastError();
 }
 
-template <class PL, int CPB, int FN, bool S16>
+template <class PL, int CPB, int FN, bool S16, bool EPI>
 hipError_t prepare_impl() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fftconv_kernel<PL, CPB, FN, S16>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fftconv_kernel<PL, CPB, FN, S16, EPI>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, PL::M * CPB * (int)sizeof(float2));
 }
 
-template <class PL, int CPB, bool S16>
+template <class PL, int CPB, bool S16, bool EPI>
 hipError_t launch_generic_impl(const KernelArgs& a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((fftconv_generic_kernel<PL, CPB, S16>), dim3(grid), dim3(PL::T * CPB), PL::M * CPB * sizeof(float2), s, a);
+    hipLaunchKernelGGL((fftconv_generic_kernel<PL, CPB, S16, EPI>), dim3(grid), dim3(PL::T * CPB), PL::M * CPB * sizeof(float2), s, a);
     return hipGetLastError();
 }
 
-template <class PL, int CPB, bool S16>
+template <class PL, int CPB, bool S16, bool EPI>
 hipError_t prepare_generic_impl() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fftconv_generic_kernel<PL, CPB, S16>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fftconv_generic_kernel<PL, CPB, S16, EPI>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, PL::M * CPB * (int)sizeof(float2));
 }
 
-template <class PL, int CPB, int FN, bool S16>
+template <class PL, int CPB, int FN, bool S16, bool EPI>
 constexpr PlanInfo make_plan() {
     return PlanInfo{PL::M, FN, PL::P, PL::T, CPB, PL::NP, PL::XL ? 1 : 0, {PL::fwd(0), PL::fwd(1), PL::fwd(2), PL::fwd(3)},
-                    PL::tw_total, PL::M * CPB * (int)sizeof(float2), &launch_impl<PL, CPB, FN, S16>, &prepare_impl<PL, CPB, FN, S16>,
-                    &launch_generic_impl<PL, CPB, S16>, &prepare_generic_impl<PL, CPB, S16>};
+                    PL::tw_total, PL::M * CPB * (int)sizeof(float2), &launch_impl<PL, CPB, FN, S16, EPI>, &prepare_impl<PL, CPB, FN, S16, EPI>,
+                    &launch_generic_impl<PL, CPB, S16, EPI>, &prepare_generic_impl<PL, CPB, S16, EPI>};
 }
 
 // M (complex points) x F/N -> plan.  Radices forward (inverse = reversed); last forward radix is P/2
 // (in-register pairing) or P (XL, cross-lane pairing) - see fftconv_kernel.hpp.
-#define ADSP_PLAN_LIST(S16)                                                      \
-    make_plan<Plan<64, 16, 2, 8, 8, 1, 1>, 16, 2, S16>(),                        \
-    make_plan<Plan<128, 16, 2, 16, 8, 1, 1>, 8, 2, S16>(),                       \
-    make_plan<Plan<128, 16, 2, 16, 8, 1, 1>, 8, 4, S16>(),                       \
-    make_plan<Plan<256, 16, 3, 4, 8, 8, 1>, 4, 2, S16>(),                        \
-    make_plan<Plan<256, 16, 3, 4, 8, 8, 1>, 4, 4, S16>(),                        \
-    make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 2, 2, S16>(),                       \
-    make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 2, 4, S16>(),                       \
-    make_plan<Plan<1024, 16, 3, 16, 8, 8, 1>, 1, 2, S16>(),                      \
-    make_plan<Plan<1024, 16, 3, 16, 8, 8, 1>, 1, 4, S16>(),                      \
-    make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 2, S16>(),                     \
-    make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 4, S16>(),                     \
-    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 2, S16>(),              \
-    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 4, S16>(),              \
-    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1, 2, S16>(),                    \
-    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1, 4, S16>(),                    \
-    make_plan<Plan<16384, 32, 4, 32, 2, 16, 16>, 1, 4, S16>()
+#define ADSP_PLAN_LIST(S16, EPI)                                                    \
+    make_plan<Plan<64, 16, 2, 8, 8, 1, 1>, 16, 2, S16, EPI>(),                        \
+    make_plan<Plan<128, 16, 2, 16, 8, 1, 1>, 8, 2, S16, EPI>(),                       \
+    make_plan<Plan<128, 16, 2, 16, 8, 1, 1>, 8, 4, S16, EPI>(),                       \
+    make_plan<Plan<256, 16, 3, 4, 8, 8, 1>, 4, 2, S16, EPI>(),                        \
+    make_plan<Plan<256, 16, 3, 4, 8, 8, 1>, 4, 4, S16, EPI>(),                        \
+    make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 2, 2, S16, EPI>(),                       \
+    make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 2, 4, S16, EPI>(),                       \
+    make_plan<Plan<1024, 16, 3, 16, 8, 8, 1>, 1, 2, S16, EPI>(),                      \
+    make_plan<Plan<1024, 16, 3, 16, 8, 8, 1>, 1, 4, S16, EPI>(),                      \
+    make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 2, S16, EPI>(),                     \
+    make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 4, S16, EPI>(),                     \
+    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 2, S16, EPI>(),              \
+    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 4, S16, EPI>(),              \
+    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1, 2, S16, EPI>(),                    \
+    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1, 4, S16, EPI>(),                    \
+    make_plan<Plan<16384, 32, 4, 32, 2, 16, 16>, 1, 4, S16, EPI>()
 
 // tables live in plans_f32.hip / plans_s16.hip (internal linkage there: host-only data, the device pass only
 // needs to see the instantiations)
 const PlanInfo* plans_f32(int* count);
 const PlanInfo* plans_s16(int* count);
+const PlanInfo* plans_f32_epi(int* count);  // same list, kernels with the fused output effect (float32 only)
 const PlanInfo* variants_f32(int* count);  // A/B alternatives, ADSP_PLAN_VARIANT=<n>
 
 }  // namespace adsp

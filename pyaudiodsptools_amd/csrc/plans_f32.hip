@@ -3,10 +3,10 @@
 
 namespace {
 using namespace adsp;
-const PlanInfo kPlans[] = {ADSP_PLAN_LIST(false)};
+const PlanInfo kPlans[] = {ADSP_PLAN_LIST(false, false)};
 // alternative kept for A/B measurements, selected with ADSP_PLAN_VARIANT=0 (tuning only)
 const PlanInfo kVariants[] = {
-    make_plan<Plan<4096, 32, 3, 16, 16, 16, 1>, 1, 2, false>(),  // 0: in-register pairing, 2 waves/transform, ~190 VGPRs
+    make_plan<Plan<4096, 32, 3, 16, 16, 16, 1>, 1, 2, false, false>(),  // 0: in-register pairing, 2 waves/transform, ~190 VGPRs
 };
 }  // namespace
 

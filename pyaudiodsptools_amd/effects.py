@@ -1,5 +1,5 @@
-"""Stateless wave-shapers of the reference as GPU effects: VolumeChange, CreateSoftClipper, CreateHardDistortion,
-CreateSaturator.
+"""The reference's elementwise effects on the GPU: VolumeChange, CreateSoftClipper, CreateHardDistortion,
+CreateSaturator, CreateTremolo and MixSignals.
 
 Each is one arithmetic expression per sample, so it runs either
   * fused: ``engine.set_epilogue(effect)`` / ``fuse(lowcut, eq, highcut, clipper)`` applies it to the filter kernel's
@@ -7,14 +7,16 @@ Each is one arithmetic expression per sample, so it runs either
   * standalone: ``effect.apply(x)`` launches the elementwise kernel of libadsp (adsp_effect_host / adsp_effect_device).
 
 Same constructor arguments, defaults and ``.apply(array) -> array`` as the reference (EffectSoftClipper.py:18-45,
-EffectHardDistortion.py:14-41, EffectSaturator.py:19-49, Utility.py:171-194).  The arithmetic is float32 (the
+EffectHardDistortion.py:14-41, EffectSaturator.py:19-49, EffectTremolo.py:19-57, Utility.py:51-72, 171-194).  The arithmetic is float32 (the
 reference computes in the dtype it is handed; its FFT devices hand it float32).
 """
 import ctypes
 
+import math
+
 import numpy as np
 
-from . import _capi
+from . import _capi, config
 
 
 class Effect:
@@ -23,6 +25,10 @@ class Effect:
 
     def params(self):
         return (0.0, 0.0, 0.0)
+
+    def _phase(self, n_samples):
+        """LFO table index of the first sample of the next n_samples (effects with a time base only)."""
+        return 0
 
     def apply(self, float_array_input, device=0, stream=None):
         """numpy array / list -> fresh float32 numpy array of the same shape; a torch CUDA tensor -> fresh CUDA tensor."""
@@ -33,13 +39,14 @@ class Effect:
             if str(x.dtype) != "torch.float32" or not x.is_cuda or not x.is_contiguous():
                 raise TypeError("device input must be a contiguous float32 CUDA tensor")
             y = x.new_empty(x.shape)
-            _capi.check(lib.adsp_effect_device(x.device.index or 0, self.op, p0, p1, p2, ctypes.c_void_p(x.data_ptr()),
+            _capi.check(lib.adsp_effect_device(x.device.index or 0, self.op, p0, p1, p2, self._phase(x.numel()),
+                                               ctypes.c_void_p(x.data_ptr()),
                                                ctypes.c_void_p(y.data_ptr()), x.numel(),
                                                ctypes.c_void_p(stream) if stream else None))
             return y
         x = np.ascontiguousarray(float_array_input, dtype=np.float32)
         y = np.empty_like(x)
-        _capi.check(lib.adsp_effect_host(int(device), self.op, p0, p1, p2, ctypes.c_void_p(x.ctypes.data),
+        _capi.check(lib.adsp_effect_host(int(device), self.op, p0, p1, p2, self._phase(x.size), ctypes.c_void_p(x.ctypes.data),
                                          ctypes.c_void_p(y.ctypes.data), x.size))
         return y
 
@@ -100,3 +107,66 @@ def CreateVolumeChange(gain_change_in_db, overflow_protection=True):
 def VolumeChange(float_array_input, gain_change_in_db, overflow_protection=True):
     """(10 ** (dB / 20)) * x, clipped to [-1, 1] unless overflow_protection is off (Utility.py:171-194)."""
     return _Volume(gain_change_in_db, overflow_protection).apply(float_array_input)
+
+
+class CreateTremolo(Effect):
+    """Amplitude modulation by a periodic LFO table: gain[n] = (sin(2 pi f n / fs) / 2 + 0.5) depth + (1 - depth), the
+    table being ``len(arange(float32(fs / f)))`` samples long and repeated end to end (EffectTremolo.py:19-47).
+
+    The only state is where in the table the next sample falls.  It follows the reference's buffer arithmetic
+    (:40-45), including its quirk: when the buffer holds exactly one chunk, ``copy[-0:]`` keeps all of it and every
+    later chunk replays the same table segment.  Standalone ``apply`` takes 1-D arrays (one stream), like the
+    reference.  Fused onto an engine (``engine.set_epilogue(tremolo)``) the table index lives in the engine, starts at
+    0 and advances with the chunks the engine filters."""
+    op = _capi.EFFECT_TREMOLO
+
+    def __init__(self, tremolo_depth=0.4, lfo_in_hertz=4.5):
+        if config.sampling_rate is None:
+            raise RuntimeError("call config.initialize(sampling_rate, chunk_size) before creating devices")
+        self.sin_sample_rate = config.sampling_rate
+        self.tremolo_depth = tremolo_depth
+        self.lfo_in_hertz = lfo_in_hertz
+        self.lfo_length = int(math.ceil(np.float32(self.sin_sample_rate / lfo_in_hertz)))
+        if not 1 <= self.lfo_length <= 1 << 23:
+            raise ValueError("LFO period must be between 1 and 2**23 samples")
+        self.reset()
+
+    @property
+    def sin_lfo(self):
+        """The LFO table as the reference exposes it (float32[lfo_length]); the GPU evaluates it in place."""
+        n = np.arange(self.lfo_length, dtype=np.float64)
+        gain = (np.sin(2 * np.pi * self.lfo_in_hertz * n / self.sin_sample_rate) / 2 + 0.5) * self.tremolo_depth
+        return (gain + (1 - self.tremolo_depth)).astype(np.float32)
+
+    def params(self):
+        return (self.tremolo_depth, self.lfo_in_hertz / self.sin_sample_rate, float(self.lfo_length))
+
+    def _phase(self, n_samples):
+        while self._buffered < n_samples:
+            self._buffered += self.lfo_length
+        phase = (-self._buffered) % self.lfo_length
+        if self._buffered != n_samples:  # the reference's copy[-0:] keeps everything in that one case
+            self._buffered -= n_samples
+        return phase
+
+    def apply(self, float_array_input, device=0, stream=None):
+        if len(getattr(float_array_input, "shape", (len(float_array_input),))) != 1:
+            raise ValueError("CreateTremolo.apply takes one 1-D stream; fuse it onto an engine for channel batches")
+        return super().apply(float_array_input, device=device, stream=stream)
+
+    def reset(self):
+        """Restart the LFO (EffectTremolo.py:49-57)."""
+        self._buffered = self.lfo_length
+
+
+def MixSignals(*args, device=0):
+    """clip(sum of the signals, -1, 1) (Utility.py:51-72).  float32 result (the reference's is float64)."""
+    arrays = [np.ascontiguousarray(a, dtype=np.float32) for a in args]
+    if not arrays:
+        raise IndexError("tuple index out of range")  # what the reference's args[0] raises
+    if any(a.shape != arrays[0].shape for a in arrays):
+        raise ValueError("Something went wrong. Make sure, that the Numpy arrays are equal in length.")
+    out = np.empty_like(arrays[0])
+    ptrs = (ctypes.c_void_p * len(arrays))(*[a.ctypes.data for a in arrays])
+    _capi.check(_capi.load().adsp_mix_host(int(device), ptrs, len(arrays), 1, ctypes.c_void_p(out.ctypes.data), out.size))
+    return out

@@ -84,9 +84,10 @@ class FirEngine:
     def upload_spectrum_device(self, d_spectrum, n_bins, stream=None):
         _capi.check(self._lib.adsp_set_spectrum_device(self._h, _ptr(d_spectrum), int(n_bins), _ptr(stream)))
 
-    def set_accumulate(self, on=True):
-        """Add results to the output buffer instead of overwriting it (later parts of a partitioned FIR)."""
-        _capi.check(self._lib.adsp_set_accumulate(self._h, 1 if on else 0))
+    def set_accumulate(self, mode=True):
+        """0/False overwrite the output buffer; 1/True add to what it holds (later parts of a partitioned FIR, a mix
+        bus); 2 add and clip the sum to [-1, 1] (the last engine of a MixSignals bus, Utility.py:51-72)."""
+        _capi.check(self._lib.adsp_set_accumulate(self._h, int(mode)))
 
     def set_epilogue(self, effect=None):
         """Fuse a stateless effect (effects.Effect) onto the kernel's output: later applies return effect(filter(x)).
@@ -174,6 +175,8 @@ class PartitionedFirEngine:
 
     def set_epilogue(self, effect=None):
         """The partial sums must be complete before a non-linear effect: it runs as one extra in-place elementwise pass."""
+        if effect is not None and effect.op == _capi.EFFECT_TREMOLO:
+            raise ValueError("the tremolo's per-channel time base is only available fused on a single-transform engine")
         self.epilogue = effect
 
     def close(self):
@@ -190,8 +193,8 @@ class PartitionedFirEngine:
         if self.epilogue is not None:
             p0, p1, p2 = (float(v) for v in self.epilogue.params())
             n = int(n_steps) * self.channels * self.chunk_size
-            _capi.check(self._lib.adsp_effect_device(self.device, self.epilogue.op, p0, p1, p2, _ptr(d_out), _ptr(d_out), n,
-                                                     _ptr(stream)))
+            _capi.check(self._lib.adsp_effect_device(self.device, self.epilogue.op, p0, p1, p2, self.epilogue._phase(n),
+                                                     _ptr(d_out), _ptr(d_out), n, _ptr(stream)))
 
     def apply_host(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32)
@@ -208,6 +211,23 @@ class PartitionedFirEngine:
 
     def synchronize(self, stream=None):
         self.engines[0].synchronize(stream)
+
+
+class MixBus:
+    """MixSignals over filtered channels in one pass each (Utility.py:51-72 after K FFT devices): engine 0 writes the
+    output buffer, the others add to it, the last one clips the sum - no separate mixing pass over HBM."""
+
+    def __init__(self, engines):
+        self.engines = list(engines)
+        if len(self.engines) < 2:
+            raise ValueError("a mix bus needs at least two engines")
+        for i, eng in enumerate(self.engines):
+            eng.set_accumulate(0 if i == 0 else (2 if i == len(self.engines) - 1 else 1))
+
+    def apply_device(self, d_inputs, d_out, n_steps=1, stream=None):
+        """d_inputs[k]: the [n_steps, C, N] device batch of engine k; all launches are ordered on `stream`."""
+        for eng, d_in in zip(self.engines, d_inputs):
+            eng.apply_device(d_in, d_out, n_steps, stream)
 
 
 def make_engine(fir: FirStream, **kw):

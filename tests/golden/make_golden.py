@@ -205,6 +205,33 @@ def main():
     fx["chain4096_lowcut_saturator_hard"] = np.concatenate([eff.apply(dev.apply(x[i * 4096:(i + 1) * 4096])) for i in range(5)])
     dev = ref.CreateEQ3BandFFT(100, 6, 700, 3, 8000, 6)  # boosts: output exceeds 1.0, the clip matters
     fx["chain4096_eq_volume_p3"] = np.concatenate([ref.VolumeChange(dev.apply(x[i * 4096:(i + 1) * 4096]), 3.0) for i in range(5)])
+    # tremolo: default (period 9800 samples), a non-integer period (48000 / 7 -> 6858-sample table), and the buffer
+    # quirk (period 1536 = 3 chunks of 512: the third chunk empties the buffer "exactly" and is replayed for ever)
+    ref.config.initialize(44100, 4096)
+    x = stream(103, 6 * 4096)
+    t = ref.CreateTremolo()
+    fx["tremolo_default"] = np.concatenate([t.apply(x[i * 4096:(i + 1) * 4096]) for i in range(6)])
+    ref.config.initialize(48000, 1000)
+    x = stream(104, 12 * 1000)
+    t = ref.CreateTremolo(0.9, 7)
+    fx["tremolo_48k_7hz"] = np.concatenate([t.apply(x[i * 1000:(i + 1) * 1000]) for i in range(12)])
+    fx["tremolo_48k_7hz_len"] = np.array([t.lfo_length])
+    ref.config.initialize(44100, 512)
+    x = stream(105, 8 * 512)
+    t = ref.CreateTremolo(0.5, 44100 / 1536)
+    fx["tremolo_quirk"] = np.concatenate([t.apply(x[i * 512:(i + 1) * 512]) for i in range(8)])
+    dev, t = ref.CreateLowCutFilter(200), ref.CreateTremolo(0.6, 10)
+    x = stream(106, 12 * 512)
+    fx["chain512_lowcut_tremolo"] = np.concatenate([t.apply(dev.apply(x[i * 512:(i + 1) * 512])) for i in range(12)])
+    dev, t = ref.CreateHighCutFilter(8000), ref.CreateTremolo(0.5, 44100 / 1536)
+    fx["chain512_highcut_tremolo_quirk"] = np.concatenate([t.apply(dev.apply(x[i * 512:(i + 1) * 512])) for i in range(12)])
+    # MixSignals: three loud signals (clipping), and three FFT devices mixed per chunk
+    a, b, c = stream(107, 4096), stream(108, 4096), stream(109, 4096)
+    fx["mix3"] = ref.MixSignals(a, b, c)
+    d1, d2, d3 = ref.CreateLowCutFilter(200), ref.CreateHighCutFilter(8000), ref.CreateEQ3BandFFT(100, 6, 700, 3, 8000, 6)
+    xs = [stream(110 + k, 6 * 512) for k in range(3)]
+    fx["chain512_mix3"] = np.concatenate([ref.MixSignals(d1.apply(xs[0][i * 512:(i + 1) * 512]), d2.apply(xs[1][i * 512:(i + 1) * 512]),
+                                                         d3.apply(xs[2][i * 512:(i + 1) * 512])) for i in range(6)])
     save("kat_effects", **fx)
 
     with open(os.path.join(HERE, "META.txt"), "w") as fh:

@@ -144,9 +144,12 @@ def test_epilogue_rejected_on_int16_engines_and_bad_codes(adsp):
     x = np.zeros(4, np.float32)
     import ctypes
     p = ctypes.c_void_p(x.ctypes.data)
-    assert lib.adsp_effect_host(0, -1, 0.0, 0.0, 0.0, p, p, 4) != 0
-    assert lib.adsp_effect_host(99, 1, 1.0, 0.0, 0.0, p, p, 4) != 0
-    assert lib.adsp_effect_host(0, 1, 1.0, 0.0, 0.0, None, p, 4) != 0
+    assert lib.adsp_effect_host(0, -1, 0.0, 0.0, 0.0, 0, p, p, 4) != 0
+    assert lib.adsp_effect_host(99, 1, 1.0, 0.0, 0.0, 0, p, p, 4) != 0
+    assert lib.adsp_effect_host(0, 1, 1.0, 0.0, 0.0, 0, None, p, 4) != 0
+    assert lib.adsp_effect_host(0, 5, 0.4, 1e-4, 100.0, 100, p, p, 4) != 0  # tremolo phase outside the table
+    assert lib.adsp_set_epilogue(dev.engine._h, 5, 0.4, 1e-4, 0.5) != 0     # table length must be a positive integer
+    assert lib.adsp_set_accumulate(dev.engine._h, 3) != 0
 
 
 def test_partitioned_engine_with_effect(adsp, golden):
@@ -167,3 +170,125 @@ def test_partitioned_engine_with_effect(adsp, golden):
     dev.engine.apply_device(d_in, d_out, 3)
     torch.cuda.synchronize()
     assert_parity(d_out.cpu().numpy().reshape(-1)[::64], want, what="device")
+
+
+TREMOLO = {
+    # golden name: (fs, chunk, seed, chunks, depth, lfo)
+    "tremolo_default": (44100, 4096, 103, 6, 0.4, 4.5),
+    "tremolo_48k_7hz": (48000, 1000, 104, 12, 0.9, 7),
+    "tremolo_quirk": (44100, 512, 105, 8, 0.5, 44100 / 1536),
+}
+
+
+@pytest.mark.parametrize("name", sorted(TREMOLO))
+def test_standalone_tremolo_matches_reference_golden(adsp, golden, name):
+    fs, n, seed, chunks, depth, lfo = TREMOLO[name]
+    adsp.config.initialize(fs, n)
+    t = adsp.CreateTremolo(depth, lfo)
+    x = seeded_stream(seed, chunks * n)
+    got = np.concatenate([t.apply(x[i * n:(i + 1) * n]) for i in range(chunks)])
+    assert_parity(got, golden["kat_effects"][name], what=name)
+    t.reset()
+    assert_parity(t.apply(x[:n]), golden["kat_effects"][name][:n], what=name + " after reset")
+
+
+@pytest.mark.parametrize("name,make,depth,lfo", [
+    ("chain512_lowcut_tremolo", lambda p: p.CreateLowCutFilter(200), 0.6, 10),
+    ("chain512_highcut_tremolo_quirk", lambda p: p.CreateHighCutFilter(8000), 0.5, 44100 / 1536),
+])
+def test_fused_tremolo_matches_reference_chain(adsp, golden, name, make, depth, lfo):
+    """Chunk by chunk, then the same 12 chunks as multi-step device launches (the quirk splits a launch)."""
+    import torch
+    n, chunks = 512, 12
+    adsp.config.initialize(44100, n)
+    x = seeded_stream(106, chunks * n)
+    want = golden["kat_effects"][name]
+    dev = make(adsp)
+    dev.engine.set_epilogue(adsp.CreateTremolo(depth, lfo))
+    got = np.concatenate([dev.apply(x[i * n:(i + 1) * n]) for i in range(chunks)])
+    assert_parity(got, want, what=name)
+    for split in [(12,), (5, 7), (2, 1, 9)]:
+        dev.reset()
+        dev.engine.set_epilogue(adsp.CreateTremolo(depth, lfo))  # restarts the LFO
+        d_in = torch.from_numpy(x.reshape(chunks, 1, n)).cuda()
+        d_out = torch.zeros_like(d_in)
+        at = 0
+        for k in split:
+            dev.engine.apply_device(d_in[at:at + k], d_out[at:at + k], k)
+            at += k
+        torch.cuda.synchronize()
+        assert_parity(d_out.cpu().numpy().reshape(-1), want, what=f"{name} split {split}")
+
+
+def test_fused_tremolo_many_channels_ring_and_generic_geometry(adsp):
+    """[steps, C, N] batches on the specialised and the generic kernel, and the zero-copy ring path, against the oracle."""
+    import torch
+    from oracle import effects_oracle as fx
+    from oracle import fftfilter_oracle as o
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    for n, fs, lfo in [(4096, 44100, 4.5), (1000, 48000, 7), (256, 44100, 300.0)]:
+        adsp.config.initialize(fs, n)
+        C, steps = 3, 7
+        dev = adsp.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5, channels=C)
+        dev.engine.set_epilogue(adsp.CreateTremolo(0.8, lfo))
+        x = seeded_stream(200 + n, steps * C * n).reshape(steps, C, n)
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.empty_like(d_in)
+        dev.engine.apply_device(d_in[:4], d_out[:4], 4)
+        for s in range(4, steps):  # then chunk by chunk through the zero-copy ring
+            slot = dev.engine.ring_acquire()
+            assert hip.hipMemcpyAsync(slot, d_in[s].data_ptr(), C * n * 4, 3, None) == 0
+            dev.engine.apply_ring(d_out[s])
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        for c in range(C):
+            od, ot = o.OracleEQ3BandFFT(100, 2, 700, -4, 8000, 5, fs, n), fx.OracleTremolo(fs, 0.8, lfo)
+            want = np.stack([ot.apply(od.apply(x[s, c])) for s in range(steps)])
+            assert_parity(got[:, c], want, what=f"N={n} channel {c}")
+
+
+def test_mix_signals_and_mix_bus(adsp, golden):
+    import torch
+    a, b, c = seeded_stream(107, 4096), seeded_stream(108, 4096), seeded_stream(109, 4096)
+    got = adsp.MixSignals(a, b, c)
+    assert got.dtype == np.float32
+    assert_parity(got, golden["kat_effects"]["mix3"], what="mix3")
+    many = [seeded_stream(300 + k, 1000) * np.float32(0.2) for k in range(19)]  # more addends than one pass takes
+    assert_parity(adsp.MixSignals(*many), np.clip(np.sum(np.stack(many).astype(np.float64), 0), -1, 1), what="mix19")
+    assert_parity(adsp.MixSignals(a), np.clip(a, -1, 1))
+    # three FFT devices summed on one output buffer; the last engine clips
+    n = 512
+    adsp.config.initialize(44100, n)
+    devs = [adsp.CreateLowCutFilter(200), adsp.CreateHighCutFilter(8000), adsp.CreateEQ3BandFFT(100, 6, 700, 3, 8000, 6)]
+    xs = [seeded_stream(110 + k, 6 * n) for k in range(3)]
+    want = golden["kat_effects"]["chain512_mix3"]
+    bus = adsp.MixBus([d.engine for d in devs])
+    d_ins = [torch.from_numpy(x.reshape(6, 1, n)).cuda() for x in xs]
+    d_out = torch.full((6, 1, n), 7.0, device="cuda")  # stale contents must not leak into the sum
+    bus.apply_device(d_ins, d_out, 6)
+    torch.cuda.synchronize()
+    assert_parity(d_out.cpu().numpy().reshape(-1), want, what="mix bus, one launch per engine")
+    for d in devs:
+        d.reset()
+    d_out.fill_(-3.0)
+    for s in range(6):
+        bus.apply_device([d[s:s + 1] for d in d_ins], d_out[s:s + 1], 1)
+    torch.cuda.synchronize()
+    assert_parity(d_out.cpu().numpy().reshape(-1), want, what="mix bus, chunk by chunk")
+    # generic geometry (N = 1000) with a middle engine in plain add mode
+    n = 1000
+    adsp.config.initialize(44100, n)
+    devs = [adsp.CreateLowCutFilter(300), adsp.CreateHighCutFilter(5000), adsp.CreateLowCutFilter(2000)]
+    xs = [seeded_stream(120 + k, 4 * n) for k in range(3)]
+    bus = adsp.MixBus([d.engine for d in devs])
+    d_ins = [torch.from_numpy(x.reshape(4, 1, n)).cuda() for x in xs]
+    d_out = torch.empty((4, 1, n), device="cuda")
+    bus.apply_device(d_ins, d_out, 4)
+    torch.cuda.synchronize()
+    from oracle import effects_oracle as fx
+    from oracle import fftfilter_oracle as o
+    od = [o.OracleLowCut(300, 44100, n), o.OracleHighCut(5000, 44100, n), o.OracleLowCut(2000, 44100, n)]
+    want = np.concatenate([fx.mix_signals(*[od[k].apply(xs[k][i * n:(i + 1) * n]) for k in range(3)]) for i in range(4)])
+    assert_parity(d_out.cpu().numpy().reshape(-1), want, what="mix bus N=1000")
