@@ -192,6 +192,34 @@ ADSP_API int adsp_kernel_time(adsp_engine* engine, double* total_ms, int* launch
 /* Block until everything this engine enqueued on `stream` is done. */
 ADSP_API int adsp_synchronize(adsp_engine* engine, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Tapped delay line: the arithmetic of the reference's CreateDelay (EffectDelay.py:60-72) and of its
+ * reverb's delay lines (_EffectReverb.py:46-58), both of which feed the output of the FFT filters into it:
+ *     out[t] = dry_gain * x[t] + sum_k tap_gain[k] * x[t - tap_delay[k]]          (per channel, zero initial history)
+ * CreateDelay(time T samples, L loops): tap_delay = T, 2T, .. LT; tap_gain = linspace(0.5, 0.1, L); dry 1 (0 if wet).
+ * float32 [step][channel][sample] batches like the FFT engines, so the two chain on the device without reshaping.
+ * ------------------------------------------------------------------------------------------------------------- */
+#define ADSP_DELAY_MAX_TAPS 1024
+typedef struct adsp_delay adsp_delay; /* opaque */
+typedef struct adsp_delay_config {
+    int device_id;
+    int chunk_size; /* N: any multiple of 4 */
+    int n_channels;
+    int n_taps;     /* 0..ADSP_DELAY_MAX_TAPS */
+} adsp_delay_config;
+/* tap_delay[k] >= 1 samples, any order; the engine keeps ceil(max delay / N) chunks of input history on the device */
+ADSP_API int adsp_delay_create(const adsp_delay_config* cfg, const int* tap_delay, const float* tap_gain, float dry_gain,
+                               adsp_delay** out);
+ADSP_API void adsp_delay_destroy(adsp_delay* line);
+ADSP_API int adsp_delay_reset(adsp_delay* line); /* history back to zeros */
+/* non-zero: add the result to what the output buffer holds (the reverb sums two lines) */
+ADSP_API int adsp_delay_set_accumulate(adsp_delay* line, int on);
+ADSP_API int adsp_delay_history_chunks(const adsp_delay* line, int* chunks);
+/* d_in / d_out: device [n_steps][n_channels][chunk_size] float32, NOT aliased; asynchronous on `stream` */
+ADSP_API int adsp_delay_apply_device(adsp_delay* line, const float* d_in, float* d_out, int n_steps, void* stream);
+/* host buffers, synchronous (with accumulate on, `out` is read as well as written) */
+ADSP_API int adsp_delay_apply_host(adsp_delay* line, const float* in, float* out, int n_steps);
+
 #ifdef __cplusplus
 }
 #endif

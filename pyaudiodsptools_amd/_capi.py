@@ -33,6 +33,11 @@ class AdspConfig(ctypes.Structure):
     ]
 
 
+class AdspDelayConfig(ctypes.Structure):
+    _fields_ = [("device_id", ctypes.c_int), ("chunk_size", ctypes.c_int), ("n_channels", ctypes.c_int),
+                ("n_taps", ctypes.c_int)]
+
+
 _c_int_p = ctypes.POINTER(ctypes.c_int)
 _c_float_p = ctypes.POINTER(ctypes.c_float)
 _engine_p = ctypes.c_void_p
@@ -59,6 +64,14 @@ SIGNATURES = {
     "adsp_mix_host": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
                                      ctypes.c_void_p, ctypes.c_size_t]),
     "adsp_set_accumulate": (ctypes.c_int, [_engine_p, ctypes.c_int]),
+    "adsp_delay_create": (ctypes.c_int, [ctypes.POINTER(AdspDelayConfig), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float,
+                                         ctypes.POINTER(ctypes.c_void_p)]),
+    "adsp_delay_destroy": (None, [ctypes.c_void_p]),
+    "adsp_delay_reset": (ctypes.c_int, [ctypes.c_void_p]),
+    "adsp_delay_set_accumulate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "adsp_delay_history_chunks": (ctypes.c_int, [ctypes.c_void_p, _c_int_p]),
+    "adsp_delay_apply_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "adsp_delay_apply_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "adsp_reset": (ctypes.c_int, [_engine_p]),
     "adsp_apply_host": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "adsp_apply_device": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),

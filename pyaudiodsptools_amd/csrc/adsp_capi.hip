@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/adsp.h"
+#include "capi_common.hpp"
 #include "plan_table.hpp"
 
 // standalone elementwise form of the fused output effects (fftconv_kernel.hpp::epilogue_value): out[i] = effect(in[i]);
@@ -53,8 +54,10 @@ __global__ void adsp_mix_kernel(MixArgs a, float* __restrict__ out, size_t n) {
 namespace {
 
 thread_local std::string g_last_error;
+}  // namespace
 
-int fail(int code, const char* fmt, ...) {
+// shared with the other translation units of the library (capi_common.hpp)
+int adsp::fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -64,12 +67,8 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e__ = (expr);                                                                   \
-        if (e__ != hipSuccess)                                                                     \
-            return fail(ADSP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
-    } while (0)
+namespace {
+using adsp::fail;
 
 using adsp::PlanInfo;
 

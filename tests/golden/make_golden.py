@@ -234,6 +234,33 @@ def main():
                                                          d3.apply(xs[2][i * 512:(i + 1) * 512])) for i in range(6)])
     save("kat_effects", **fx)
 
+    # ---- I: callers that embed the FFT filters: CreateDelay and the private reverb -------------
+    dl = {}
+    ref.config.initialize(44100, 4096)
+    x = stream(130, 14 * 4096)
+    for tag, kw in [("default", {}), ("wet", {"wet": True}), ("300ms_4loops", {"time_in_ms": 300, "feedback_loops": 4})]:
+        d = ref.CreateDelay(**kw)
+        dl["delay4096_" + tag] = np.concatenate([d.apply(x[i * 4096:(i + 1) * 4096].copy()) for i in range(14)])
+    ref.config.initialize(44100, 512)
+    x = stream(131, 12 * 512)
+    d = ref.CreateDelay(10, 5)      # 441-sample taps: several land inside one chunk
+    dl["delay512_10ms_5loops"] = np.concatenate([d.apply(x[i * 512:(i + 1) * 512].copy()) for i in range(12)])
+    d = ref.CreateDelay(7.3, 1, wet=True)   # 321 samples, one tap
+    dl["delay512_7ms_wet"] = np.concatenate([d.apply(x[i * 512:(i + 1) * 512].copy()) for i in range(12)])
+    d = ref.CreateDelay(100, 0)     # no taps at all
+    dl["delay512_noloops"] = np.concatenate([d.apply(x[i * 512:(i + 1) * 512].copy()) for i in range(3)])
+    from pyAudioDspTools import _EffectReverb as ref_reverb
+    with contextlib.redirect_stdout(io.StringIO()):  # the delay lines print their tap spacing
+        rv = ref_reverb.CreateReverb()
+    x = stream(132, 40 * 512)
+    dl["reverb512_default"] = np.concatenate([rv.applyreverb(x[i * 512:(i + 1) * 512].copy()) for i in range(40)])
+    ref.config.initialize(48000, 256)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rv = ref_reverb.CreateReverb(800)
+    x = stream(133, 60 * 256)
+    dl["reverb256_800ms_48k"] = np.concatenate([rv.applyreverb(x[i * 256:(i + 1) * 256].copy()) for i in range(60)])
+    save("kat_callers", **dl)
+
     with open(os.path.join(HERE, "META.txt"), "w") as fh:
         for k in sorted(meta):
             fh.write(f"{k} = {meta[k]}\n")
