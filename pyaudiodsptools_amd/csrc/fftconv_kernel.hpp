@@ -236,6 +236,9 @@ struct Dft {
 // ------------------------------------------------------------------------------------------
 template <int R, bool SWZ>
 __device__ __forceinline__ int lds_phys(int a) {
+#if ADSP_ABLATE & 1024
+    a = a < 3999 ? a : 3999;  // tuning only (wrong results): what would 5 workgroups per CU buy at M = 4096?
+#endif
     if constexpr (!SWZ) {
         return a;
     } else {

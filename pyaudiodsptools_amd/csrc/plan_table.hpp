@@ -19,34 +19,42 @@ struct PlanInfo {
     hipError_t (*prepare_generic)();
 };
 
+template <class PL, int CPB>
+constexpr int lds_bytes() {
+#if ADSP_ABLATE & 1024
+    if (PL::M == 4096) return 32000;
+#endif
+    return PL::M * CPB * (int)sizeof(float2);
+}
+
 template <class PL, int CPB, int FN, bool S16, bool EPI>
 hipError_t launch_impl(const KernelArgs& a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((fftconv_kernel<PL, CPB, FN, S16, EPI>), dim3(grid), dim3(PL::T * CPB), PL::M * CPB * sizeof(float2), s, a);
+    hipLaunchKernelGGL((fftconv_kernel<PL, CPB, FN, S16, EPI>), dim3(grid), dim3(PL::T * CPB), (lds_bytes<PL, CPB>()), s, a);
     return hipGetLastError();
 }
 
 template <class PL, int CPB, int FN, bool S16, bool EPI>
 hipError_t prepare_impl() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&fftconv_kernel<PL, CPB, FN, S16, EPI>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, PL::M * CPB * (int)sizeof(float2));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<PL, CPB>());
 }
 
 template <class PL, int CPB, bool S16, bool EPI>
 hipError_t launch_generic_impl(const KernelArgs& a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((fftconv_generic_kernel<PL, CPB, S16, EPI>), dim3(grid), dim3(PL::T * CPB), PL::M * CPB * sizeof(float2), s, a);
+    hipLaunchKernelGGL((fftconv_generic_kernel<PL, CPB, S16, EPI>), dim3(grid), dim3(PL::T * CPB), (lds_bytes<PL, CPB>()), s, a);
     return hipGetLastError();
 }
 
 template <class PL, int CPB, bool S16, bool EPI>
 hipError_t prepare_generic_impl() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&fftconv_generic_kernel<PL, CPB, S16, EPI>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, PL::M * CPB * (int)sizeof(float2));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<PL, CPB>());
 }
 
 template <class PL, int CPB, int FN, bool S16, bool EPI>
 constexpr PlanInfo make_plan() {
     return PlanInfo{PL::M, FN, PL::P, PL::T, CPB, PL::NP, PL::XL ? 1 : 0, {PL::fwd(0), PL::fwd(1), PL::fwd(2), PL::fwd(3)},
-                    PL::tw_total, PL::M * CPB * (int)sizeof(float2), &launch_impl<PL, CPB, FN, S16, EPI>, &prepare_impl<PL, CPB, FN, S16, EPI>,
+                    PL::tw_total, lds_bytes<PL, CPB>(), &launch_impl<PL, CPB, FN, S16, EPI>, &prepare_impl<PL, CPB, FN, S16, EPI>,
                     &launch_generic_impl<PL, CPB, S16, EPI>, &prepare_generic_impl<PL, CPB, S16, EPI>};
 }
 

@@ -1,0 +1,15 @@
+#!/bin/bash
+# build a tuning variant of libadsp into abl/<name>.so:  tools/build_variant.sh name -DADSP_MIN_WAVES=5 ...
+set -e
+name=$1; shift
+root="$(cd "$(dirname "$0")/.." && pwd)"
+tmp=$(mktemp -d)
+mkdir -p "$root/abl"
+cd "$root/pyaudiodsptools_amd/csrc"
+for f in adsp_capi adsp_delay plans_f32 plans_s16 plans_f32_epi; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fvisibility=hidden -Wno-unused-function -fno-slp-vectorize "$@" -c -o $tmp/$f.o $f.hip &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/abl/$name.so" $tmp/*.o
+rm -rf $tmp
+echo "built abl/$name.so"
