@@ -196,6 +196,17 @@ struct adsp_engine {
     char* stage_in;
     char* stage_out;
     size_t stage_elems;  // capacity in samples
+    // small host calls skip the staging copies: the kernel reads a pinned, device-mapped copy of the caller's input
+    // and writes the result straight into pinned host memory (two input slots: the ring update of call k may still be
+    // reading slot k % 2 while the caller fills the other)
+    char* pin_in[2];
+    char* pin_out;
+    size_t pin_bytes;
+    int pin_slot;
+    bool pin_busy[2];
+    hipEvent_t ev_pin[2];
+    hipEvent_t ev_kernel;   // recorded right after the kernel when want_kernel_event is set
+    bool want_kernel_event;
     bool timing;
     hipStream_t copy_stream;  // ring update of multi-step launches runs beside the kernel
     hipEvent_t ev_in_ready, ev_copy_done;
@@ -303,6 +314,7 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
         HIP_TRY(hipEventRecord(ev.first, stream));
     }
     HIP_TRY(e->generic ? pl.launch_generic(a, (int)grid, stream) : pl.launch(a, (int)grid, stream));
+    if (e->want_kernel_event) HIP_TRY(hipEventRecord(e->ev_kernel, stream));
     if (e->timing) {
         HIP_TRY(hipEventRecord(ev.second, stream));
         e->timed.push_back(ev);
@@ -416,6 +428,12 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     e->have_spectrum = false;
     e->stage_in = e->stage_out = nullptr;
     e->stage_elems = 0;
+    e->pin_in[0] = e->pin_in[1] = e->pin_out = nullptr;
+    e->pin_bytes = 0;
+    e->pin_slot = 0;
+    e->pin_busy[0] = e->pin_busy[1] = false;
+    e->ev_pin[0] = e->ev_pin[1] = e->ev_kernel = nullptr;
+    e->want_kernel_event = false;
     e->timing = false;
     e->copy_stream = nullptr;
     e->ev_in_ready = e->ev_copy_done = nullptr;
@@ -464,6 +482,10 @@ int adsp_destroy(adsp_engine* e) {
     if (e->ev_copy_done) (void)hipEventDestroy(e->ev_copy_done);
     if (e->stage_in) (void)hipFree(e->stage_in);
     if (e->stage_out) (void)hipFree(e->stage_out);
+    for (char* p : {e->pin_in[0], e->pin_in[1], e->pin_out})
+        if (p) (void)hipHostFree(p);
+    for (hipEvent_t ev : {e->ev_pin[0], e->ev_pin[1], e->ev_kernel})
+        if (ev) (void)hipEventDestroy(ev);
     for (auto& v : {&e->timed, &e->free_ev})
         for (auto& p : *v) {
             (void)hipEventDestroy(p.first);
@@ -722,7 +744,7 @@ int apply_device_run(adsp_engine* e, const void* d_in, void* d_out, int n_steps,
     for (int i = 0; i < cnt; ++i) {
         const int slot = (e->ring_pos + 1 + i) % S;
         const char* src = static_cast<const char*>(d_in) + (size_t)(n_steps - cnt + i) * plane;
-        HIP_TRY(hipMemcpyAsync(e->ring + (size_t)slot * plane, src, plane, hipMemcpyDeviceToDevice, cs));
+        HIP_TRY(hipMemcpyAsync(e->ring + (size_t)slot * plane, src, plane, hipMemcpyDefault, cs));  // src: device or mapped host
     }
     if (side) {
         // join: everything the caller enqueues on `stream` after this call (and "stream finished => d_in may be
@@ -759,12 +781,57 @@ int adsp_apply_ring(adsp_engine* e, void* d_out, void* stream_v) {
     return ADSP_OK;
 }
 
+namespace {
+constexpr size_t kHostDirectMax = 2u << 20;  // bytes per direction up to which a host call takes the direct path
+
+// One launch, no staging copies: input = pinned host memory the kernel reads over PCIe, output = pinned host memory the
+// kernel writes; the call returns as soon as the KERNEL is done (event), the ring update keeps running behind it.
+int apply_host_direct(adsp_engine* e, const void* in, void* out, int n_steps, size_t bytes) {
+    if (bytes > e->pin_bytes) {
+        HIP_TRY(hipDeviceSynchronize());  // nothing may still be reading the old buffers
+        for (char** p : {&e->pin_in[0], &e->pin_in[1], &e->pin_out}) {
+            if (*p) (void)hipHostFree(*p);
+            *p = nullptr;
+        }
+        e->pin_bytes = 0;
+        e->pin_busy[0] = e->pin_busy[1] = false;
+        size_t cap = 64u << 10;
+        while (cap < bytes) cap *= 2;
+        for (char** p : {&e->pin_in[0], &e->pin_in[1], &e->pin_out}) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(p), cap, hipHostMallocMapped));
+        for (hipEvent_t* ev : {&e->ev_pin[0], &e->ev_pin[1], &e->ev_kernel})
+            if (!*ev) HIP_TRY(hipEventCreate(ev));
+        e->pin_bytes = cap;
+    }
+    const int b = e->pin_slot ^= 1;
+    if (e->pin_busy[b]) {  // the ring update two calls ago read this slot
+        HIP_TRY(hipEventSynchronize(e->ev_pin[b]));
+        e->pin_busy[b] = false;
+    }
+    memcpy(e->pin_in[b], in, bytes);
+    if (e->accumulate) memcpy(e->pin_out, out, bytes);  // the kernel adds to what the output holds
+    void *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&d_in, e->pin_in[b], 0));
+    HIP_TRY(hipHostGetDevicePointer(&d_out, e->pin_out, 0));
+    e->want_kernel_event = true;
+    const int rc = adsp_apply_device(e, d_in, d_out, n_steps, nullptr);
+    e->want_kernel_event = false;
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(e->ev_pin[b], nullptr));  // behind the ring update
+    e->pin_busy[b] = true;
+    HIP_TRY(hipEventSynchronize(e->ev_kernel));
+    memcpy(out, e->pin_out, bytes);
+    return ADSP_OK;
+}
+}  // namespace
+
 int adsp_apply_host(adsp_engine* e, const void* in, void* out, int n_steps) {
     if (!e || !in || !out) return fail(ADSP_ERR_ARG, "NULL argument");
     if (n_steps <= 0) return fail(ADSP_ERR_ARG, "n_steps must be positive");
+    if (!e->have_spectrum) return fail(ADSP_ERR_STATE, "adsp_set_spectrum has not been called");
     int rc = set_device(e);
     if (rc) return rc;
     const size_t elems = (size_t)n_steps * e->plane();
+    if (elems * e->ssize() <= kHostDirectMax) return apply_host_direct(e, in, out, n_steps, elems * e->ssize());
     if (elems > e->stage_elems) {
         HIP_TRY(hipDeviceSynchronize());
         if (e->stage_in) (void)hipFree(e->stage_in);
@@ -776,6 +843,7 @@ int adsp_apply_host(adsp_engine* e, const void* in, void* out, int n_steps) {
         e->stage_elems = elems;
     }
     HIP_TRY(hipMemcpy(e->stage_in, in, elems * e->ssize(), hipMemcpyHostToDevice));
+    if (e->accumulate) HIP_TRY(hipMemcpy(e->stage_out, out, elems * e->ssize(), hipMemcpyHostToDevice));
     if ((rc = adsp_apply_device(e, e->stage_in, e->stage_out, n_steps, nullptr))) return rc;
     HIP_TRY(hipMemcpy(out, e->stage_out, elems * e->ssize(), hipMemcpyDeviceToHost));
     return ADSP_OK;
