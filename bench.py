@@ -278,7 +278,7 @@ def main():
                     ("(library input ring)" if args.mode == "stream" else "([steps, channels, chunk] batches)"),
             "config": {"workload": f"{FILTER_NAMES[args.filter]}{'' if args.effect == 'none' else ' -> ' + args.effect} @ {args.fs} Hz, {C} mono channels x {N}-sample chunks per GPU",
                        "channels_per_gpu": C, "chunk_size": N, "mode": mode_key, "steps_per_launch": main_run.spl,
-                       "fft_size": eng.geometry.fft_size,
+                       "fft_size": eng.geometry.fft_size, "spectrum": "real (zero-phase kernel)" if eng.real_spectrum else "complex",
                        "outputs_per_transform": (N if args.mode == "stream" else eng.block_outputs),
                        "parallelism": f"channel-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -70,7 +70,9 @@ typedef struct adsp_engine adsp_engine; /* opaque */
  * samples starting at circular index out_offset of the inverse transform.
  *
  * Single reference device with chunk N (L = N/2-1 taps, d = (L-1)/2):
- *   low/high cut : fft_size 2N, history_chunks 2, lookback N + N/4, out_offset N/2  (kernel delayed by 1 tap)
+ *   low/high cut : fft_size 2N, history_chunks 2, lookback N + N/4, out_offset N/4  (symmetric kernel centred on
+ *                  circular index 0: its spectrum is real, which adsp_set_spectrum detects - every imaginary part
+ *                  exactly 0 - and answers with a cheaper spectrum stage, 3 real constants per bin pair)
  *   3-band EQ    : fft_size 2N, history_chunks 2, lookback 2N - N/4, out_offset N  (kernel delayed by 1 tap)
  */
 typedef struct adsp_config {
@@ -118,6 +120,10 @@ ADSP_API int adsp_set_spectrum(adsp_engine* engine, const float* spectrum_interl
 
 /* Same, from device memory (e.g. after an RCCL broadcast). */
 ADSP_API int adsp_set_spectrum_device(adsp_engine* engine, const float* d_spectrum_interleaved, int n_bins, void* stream);
+
+/* 1 when the spectrum last set is real (every imaginary part exactly 0 - a symmetric kernel centred on circular index
+ * 0): the kernel then runs its cheaper spectrum stage.  0 otherwise. */
+ADSP_API int adsp_spectrum_is_real(const adsp_engine* engine, int* is_real);
 
 /* Samples kept per transform in multi-step launches (apply_device with n_steps > 1).  Default is
  * chunk_size; any multiple of 2*threads_per_transform up to fft_size - out_offset is valid and

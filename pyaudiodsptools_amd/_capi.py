@@ -54,6 +54,7 @@ SIGNATURES = {
     "adsp_set_spectrum": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_int]),
     "adsp_set_spectrum_device": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "adsp_set_block_outputs": (ctypes.c_int, [_engine_p, ctypes.c_int]),
+    "adsp_spectrum_is_real": (ctypes.c_int, [_engine_p, _c_int_p]),
     "adsp_set_epilogue": (ctypes.c_int, [_engine_p, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float]),
     "adsp_effect_device": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                           ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),

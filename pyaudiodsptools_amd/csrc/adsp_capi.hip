@@ -193,6 +193,7 @@ struct adsp_engine {
     float2* pair0;
     char* zeros;   // 4*chunk_size zero bytes
     bool have_spectrum;
+    bool real_spec;  // every Im H == 0: the kernel takes the 3-real-constants-per-pair path
     char* stage_in;
     char* stage_out;
     size_t stage_elems;  // capacity in samples
@@ -236,9 +237,30 @@ int upload_pairs(adsp_engine* e, const float* H, hipStream_t stream) {
         const int lo = 32 * (t >> 6) + (t & 31);
         return (t & 32) ? (t == 32 ? T / 2 : T - lo) : lo;
     };
+    // A real spectrum (zero-phase kernel) makes c1, c4 real and c2 imaginary: 3 floats per pair instead of 6.
+    bool real_spec = true;
+    for (int k = 0; k <= M && real_spec; ++k) real_spec = H[2 * k + 1] == 0.0f;
+    if (getenv("ADSP_FORCE_COMPLEX")) real_spec = false;  // tuning: A/B the two spectrum stages on the same filter
+    e->real_spec = real_spec;
     // float4 layout [h][3][T]: (wc,g1) of pair 2h, (g2 of 2h, wc of 2h+1), (g1,g2) of 2h+1
     std::vector<float4> tab((size_t)(npairs / 2) * 3 * T, make_float4(0.f, 0.f, 0.f, 0.f));
-    for (int h = 0; h < npairs / 2; ++h)
+    if (real_spec) {
+        // [g][3][T] float4 = (c1.re, c4.re, c2.im) of pairs 4g .. 4g+3
+        std::vector<float> flat(12);
+        for (int g = 0; g < npairs / 4; ++g)
+            for (int tid = 0; tid < T; ++tid) {
+                if (tid == 0 || (pl.XL && tid == 32)) continue;
+                for (int q = 0; q < 4; ++q) {
+                    const PairEntry pe = pair_entry(H, M, first_bin(tid) + D * (4 * g + q));
+                    flat[3 * q + 0] = pe.wc.x;
+                    flat[3 * q + 1] = pe.g2.x;
+                    flat[3 * q + 2] = pe.g1.y;
+                }
+                for (int j = 0; j < 3; ++j)
+                    tab[(size_t)(g * 3 + j) * T + tid] = make_float4(flat[4 * j], flat[4 * j + 1], flat[4 * j + 2], flat[4 * j + 3]);
+            }
+    }
+    for (int h = 0; h < npairs / 2 && !real_spec; ++h)
         for (int tid = 0; tid < T; ++tid) {
             if (tid == 0 || (pl.XL && tid == 32)) continue;  // self-paired butterflies: tab0
             const PairEntry a = pair_entry(H, M, first_bin(tid) + D * (2 * h));
@@ -288,6 +310,7 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
     a.nh = c.history_chunks;
     a.inv_n = 1.0f / (float)c.chunk_size;
     a.accumulate = e->accumulate;
+    a.real_spec = e->real_spec ? 1 : 0;
     a.epi_phase = e->epi_phase;
     a.epi_op = e->epi_op;
     a.epi_p0 = e->epi_p[0];
@@ -426,6 +449,7 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     e->pair0 = nullptr;
     e->zeros = nullptr;
     e->have_spectrum = false;
+    e->real_spec = false;
     e->stage_in = e->stage_out = nullptr;
     e->stage_elems = 0;
     e->pin_in[0] = e->pin_in[1] = e->pin_out = nullptr;
@@ -514,6 +538,13 @@ int adsp_set_spectrum_device(adsp_engine* e, const float* d_spectrum, int n_bins
     HIP_TRY(hipMemcpy(host.data(), d_spectrum, host.size() * sizeof(float), hipMemcpyDeviceToHost));
     HIP_TRY(hipDeviceSynchronize());
     return upload_pairs(e, host.data(), nullptr);
+}
+
+int adsp_spectrum_is_real(const adsp_engine* e, int* is_real) {
+    if (!e || !is_real) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (!e->have_spectrum) return fail(ADSP_ERR_STATE, "adsp_set_spectrum has not been called");
+    *is_real = e->real_spec ? 1 : 0;
+    return ADSP_OK;
 }
 
 int adsp_set_block_outputs(adsp_engine* e, int v) {

@@ -80,6 +80,7 @@ struct KernelArgs {
     int N;                 // chunk size (generic-geometry kernel only; the specialised kernels know it at compile time)
     int nh;                // history chunks (generic-geometry kernel only)
     float inv_n;           // 1 / N
+    int real_spec;         // the spectrum is real (zero-phase kernel): `pair` holds 3 real constants per bin pair
     int epi_op;            // fused output epilogue (0 = none), see apply_epilogue
     float epi_p0, epi_p1, epi_p2;
     int epi_phase;         // tremolo: LFO table index of this launch's output sample 0
@@ -449,13 +450,47 @@ __device__ __forceinline__ void pair_op(float& zar, float& zai, float& zbr, floa
     zbi = -ti;
 }
 
+// The same matrix for a REAL spectrum (a symmetric kernel centred on circular index 0, e.g. the reference's low/high
+// cut filters): s and d are real, so c1 = (a, 0), c4 = (b, 0), c2 = (0, e) - 8 multiply-adds and 12 bytes per pair.
+__device__ __forceinline__ void pair_op_real(float& zar, float& zai, float& zbr, float& zbi, float a, float b, float e) {
+    const float o1r = a * zar + e * zbi;
+    const float o1i = a * zai + e * zbr;
+    const float tr = b * zbr + e * zai;
+    const float ti = b * zbi + e * zar;
+    zar = o1r;
+    zai = o1i;
+    zbr = tr;
+    zbi = ti;
+}
+
+// real-spectrum table: [g][3][T] float4 = (a, b, e) of pairs 4g .. 4g+3 of thread t
+__device__ __forceinline__ void load_real_group(const float4* __restrict__ pair, int g, int T, int t, float (&c)[12]) {
+    const float4 f0 = pair[(g * 3 + 0) * T + t], f1 = pair[(g * 3 + 1) * T + t], f2 = pair[(g * 3 + 2) * T + t];
+    c[0] = f0.x; c[1] = f0.y; c[2] = f0.z; c[3] = f0.w;
+    c[4] = f1.x; c[5] = f1.y; c[6] = f1.z; c[7] = f1.w;
+    c[8] = f2.x; c[9] = f2.y; c[10] = f2.z; c[11] = f2.w;
+}
+
 template <class PL>
 __device__ __forceinline__ void spectrum_stage(float (&xr)[PL::P], float (&xi)[PL::P],
                                                const float4* __restrict__ pair, const float2* __restrict__ pair0,
-                                               int tid) {
+                                               int tid, bool real_spec) {
     constexpr int R = PL::RL, T = PL::T;
+    static_assert(R % 4 == 0, "real-spectrum table packs four pairs per group");
     // registers: butterfly a (j = ja) output r -> [2r];  butterfly b (j = jb) output r -> [2r+1]
-    if (tid != 0) {
+    if (tid != 0 && real_spec) {  // wave-uniform flag
+#pragma unroll
+        for (int g = 0; g < R / 4; ++g) {
+            float c[12];
+            load_real_group(pair, g, T, tid, c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * g + q;
+                pair_op_real(xr[2 * r], xi[2 * r], xr[2 * (R - 1 - r) + 1], xi[2 * (R - 1 - r) + 1], c[3 * q], c[3 * q + 1],
+                             c[3 * q + 2]);
+            }
+        }
+    } else if (tid != 0) {
         // k = tid + 2T*r pairs with M-k = jb + 2T*(R-1-r); two pairs share three 16-byte table loads
 #pragma unroll
         for (int h = 0; h < R / 2; ++h) {
@@ -526,9 +561,23 @@ __device__ __forceinline__ void exchange_upper_half(float (&xr)[P], float (&xi)[
 template <class PL>
 __device__ __forceinline__ void spectrum_stage_xl(float (&xr)[PL::P], float (&xi)[PL::P],
                                                   const float4* __restrict__ pair, const float2* __restrict__ pair0,
-                                                  int t) {
+                                                  int t, bool real_spec) {
     constexpr int R = PL::P, T = PL::T;
-    if (t != 0 && t != 32) {
+    static_assert(R % 8 == 0, "real-spectrum table packs four pairs per group");
+    if (t != 0 && t != 32 && real_spec) {  // wave-uniform flag
+        exchange_upper_half<R>(xr, xi);
+#pragma unroll
+        for (int g = 0; g < R / 8; ++g) {
+            float c[12];
+            load_real_group(pair, g, T, t, c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * g + q;
+                pair_op_real(xr[r], xi[r], xr[(R - 1 - r) ^ 1], xi[(R - 1 - r) ^ 1], c[3 * q], c[3 * q + 1], c[3 * q + 2]);
+            }
+        }
+        exchange_upper_half<R>(xr, xi);
+    } else if (t != 0 && t != 32) {
         exchange_upper_half<R>(xr, xi);
 #pragma unroll
         for (int h = 0; h < R / 4; ++h) {
@@ -905,9 +954,9 @@ __device__ __forceinline__ void transform_block(float (&xr)[PL::P], float (&xi)[
     run_passes<PL, false, 0>(xr, xi, lds, a.tw, tid, ja, jb);
 #if !(ADSP_ABLATE & 256)
     if constexpr (PL::XL)
-        spectrum_stage_xl<PL>(xr, xi, a.pair, a.pair0, tid);
+        spectrum_stage_xl<PL>(xr, xi, a.pair, a.pair0, tid, a.real_spec != 0);
     else
-        spectrum_stage<PL>(xr, xi, a.pair, a.pair0, tid);
+        spectrum_stage<PL>(xr, xi, a.pair, a.pair0, tid, a.real_spec != 0);
 #endif
     run_passes<PL, true, 0>(xi, xr, lds, a.tw, tid, ja, jb);  // inverse = forward on swapped parts
 }

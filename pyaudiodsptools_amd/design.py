@@ -105,8 +105,10 @@ class Geometry:
     history_chunks: int
     lookback: int
     out_offset: int
-    shift: int           # zero taps prepended so that out_offset is aligned
+    shift: int           # circular index of taps[0] in the F-point kernel buffer: > 0 delays the kernel so that
+                         # out_offset is aligned, < 0 (zero_phase) centres a symmetric kernel on index 0
     max_block_outputs: int
+    zero_phase: bool = False  # the spectrum is real: the engine takes its 3-constants-per-bin-pair path
 
 
 def overlap_save_geometry(fir: FirStream, fft_mult: int = 0, optimize_for: str = "stream") -> Geometry:
@@ -128,18 +130,28 @@ def overlap_save_geometry(fir: FirStream, fft_mult: int = 0, optimize_for: str =
     if d_total <= 0:
         raise ValueError("non-causal stream")
     lookback = -(-(d_total + m - 1) // g) * g
-    shift = (-(lookback - d_total)) % g
+    centre = (m - 1) // 2
+    symmetric = m % 2 == 1 and np.abs(fir.taps - fir.taps[::-1]).max() <= 1e-13 * np.abs(fir.taps).max()
+    zero_phase = bool(symmetric and (d_total + centre) % g == 0)
+    if zero_phase:
+        # A symmetric kernel centred on circular index 0 has a REAL spectrum (half the spectrum-stage arithmetic and
+        # table traffic in the kernel).  Valid circular indices are centre .. F-1-centre; the kept slice starts at
+        # lookback - delay - centre, a multiple of N/4 whenever delay + centre is (the reference's low/high cut
+        # filters: delay = N - d, centre = d).
+        shift = -centre
+    else:
+        shift = (-(lookback - d_total)) % g
     out_offset = lookback - d_total + shift
-    if not fft_mult and optimize_for == "batch" and (2 * n - out_offset) // g * g <= n and out_offset + n <= 4 * n:
+    if not fft_mult and optimize_for == "batch" and (2 * n - max(0, -shift) - out_offset) // g * g <= n and out_offset + n <= 4 * n - max(0, -shift):
         fft_mult = 4
     for f in ((2 * n, 4 * n) if not fft_mult else (fft_mult * n,)):
-        if out_offset + n <= f:
+        if out_offset + n <= f - max(0, -shift):
             break
     else:
         raise ValueError(f"kernel of {m} taps does not fit a {fft_mult or 4}N transform at N={n}")
     hist = -(-lookback // n)
-    vmax = ((f - out_offset) // g) * g
-    return Geometry(f, hist, lookback, out_offset, shift, vmax)
+    vmax = ((f - max(0, -shift) - out_offset) // g) * g
+    return Geometry(f, hist, lookback, out_offset, shift, vmax, zero_phase)
 
 
 PCM16_GAIN = 32767.0 / 32768.0  # int16 -> float (/32768, Utility.py:237) and float -> int16 (*32767, Utility.py:306)
@@ -218,6 +230,8 @@ def engine_spectrum(fir: FirStream, geo: Geometry, gain: float = 1.0) -> np.ndar
 
     `gain` scales the kernel; int16 engines fold the reference's two PCM conversions into it (PCM16_GAIN)."""
     padded = np.zeros(geo.fft_size)
-    padded[geo.shift: geo.shift + len(fir.taps)] = fir.taps * gain
-    spec = np.fft.rfft(padded).astype(np.complex64)
-    return np.ascontiguousarray(spec).view(np.float32)
+    padded[(geo.shift + np.arange(len(fir.taps))) % geo.fft_size] = fir.taps * gain
+    spec = np.fft.rfft(padded)
+    if geo.zero_phase:
+        spec = spec.real + 0j  # circularly even kernel: the imaginary part is round-off, and exact zeros select the real path
+    return np.ascontiguousarray(spec.astype(np.complex64)).view(np.float32)

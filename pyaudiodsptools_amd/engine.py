@@ -81,6 +81,13 @@ class FirEngine:
         spec = np.ascontiguousarray(spectrum_f32, dtype=np.float32)
         _capi.check(self._lib.adsp_set_spectrum(self._h, _ptr(spec), spec.size // 2))
 
+    @property
+    def real_spectrum(self):
+        """True when the engine runs the real-spectrum stage (symmetric kernel centred on circular index 0)."""
+        flag = ctypes.c_int(0)
+        _capi.check(self._lib.adsp_spectrum_is_real(self._h, ctypes.byref(flag)))
+        return bool(flag.value)
+
     def upload_spectrum_device(self, d_spectrum, n_bins, stream=None):
         _capi.check(self._lib.adsp_set_spectrum_device(self._h, _ptr(d_spectrum), int(n_bins), _ptr(stream)))
 

@@ -46,12 +46,15 @@ def test_geometry_matches_header_documentation():
     for n in (64, 512, 4096, 8192):
         lc = design.FirStream(design.lowcut_kernel(800, 44100, n), n)
         g = design.overlap_save_geometry(lc)
-        assert (g.fft_size, g.history_chunks, g.lookback, g.out_offset, g.shift, g.max_block_outputs) == \
-            (2 * n, 2, n + n // 4, n // 2, 1, n + n // 2)
+        # symmetric kernel centred on circular index 0 (real spectrum): the kept slice starts after d = N/4 - 1 wrapped taps
+        assert (g.fft_size, g.history_chunks, g.lookback, g.out_offset, g.shift, g.max_block_outputs, g.zero_phase) == \
+            (2 * n, 2, n + n // 4, n // 4, -(n // 4 - 1), n + n // 2, True)
+        spec = design.engine_spectrum(lc, g)
+        assert np.all(spec[1::2] == 0) and np.abs(spec[0::2]).max() > 0.5
         eq = design.FirStream(design.eq3_composite(100, 2, 700, -4, 8000, 5, 44100, n), n)
         g = design.overlap_save_geometry(eq)
-        assert (g.fft_size, g.history_chunks, g.lookback, g.out_offset, g.shift, g.max_block_outputs) == \
-            (2 * n, 2, 2 * n - n // 4, n, 1, n)
+        assert (g.fft_size, g.history_chunks, g.lookback, g.out_offset, g.shift, g.max_block_outputs, g.zero_phase) == \
+            (2 * n, 2, 2 * n - n // 4, n, 1, n, False)  # not symmetric: the mid band sits d samples later than the shelves
         hc = design.FirStream(design.highcut_kernel(8000, 44100, n), n)
         ch = lc.then(eq).then(hc)
         g = design.overlap_save_geometry(ch)
