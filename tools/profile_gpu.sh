@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 64 --warmup 8 --no-cpu-baseline $*"
+BENCH="python $ROOT/bench.py --steps 128 --warmup 32 --no-cpu-baseline --no-stream-extra $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $BENCH > $OUT/trace.log 2>&1
 i=0
 for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
@@ -25,8 +25,8 @@ def emit(*a):
     print(*a); print(*a, file=summ)
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
     emit("== kernel stats", os.path.relpath(f, out))
-    for row in list(csv.reader(open(f)))[:8]:
-        emit("  ", ",".join(row))
+    for row in list(csv.reader(open(f)))[:6]:
+        emit("  ", ",".join(c[:110] for c in row))
 for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
     if not os.path.isdir(d): continue
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
