@@ -170,14 +170,16 @@ class Runner:
             self.outs = [torch.empty((spl, C, N), device=dev, dtype=dt) for _ in range(2)]
 
             def run(k_steps):
-                for i in range(k_steps // spl):
+                full, rest = divmod(k_steps, spl)
+                for i in range(full):
                     eng.apply_device(self.ins[i % n_in], self.outs[i % 2], spl, sptr)
+                if rest:  # exactly k_steps: one shorter launch at the end
+                    eng.apply_device(self.ins[full % n_in][:rest], self.outs[full % 2][:rest], rest, sptr)
         self.run = run
 
     def measure(self, steps, warm, barrier=None):
         torch, eng = self.torch, self.eng
-        steps = max(self.spl, (steps // self.spl) * self.spl)
-        warm = -(-warm // self.spl) * self.spl if warm else 0
+        steps = max(1, steps)
         self.run(warm)
         torch.cuda.synchronize()
         if barrier:
@@ -250,7 +252,7 @@ def main():
         eng = main_run.eng
         value = C * N * world * steps / wall / 1e6
         per_launch_s = kern_ms / 1e3 / launches
-        samples_per_launch = C * N * (steps // launches)
+        samples_per_launch = C * N * steps / launches  # average: a --steps that is no multiple of the launch size ends short
         achieved = alg_bytes * samples_per_launch / per_launch_s / 1e9
         mode_key = "stream" if args.mode == "stream" else "batch"
         traffic = None
@@ -258,7 +260,7 @@ def main():
         if os.path.exists(tf):
             try:
                 rec = json.load(open(tf)).get(f"{args.filter}_{C}x{N}_{mode_key}" + ("" if args.io == "f32" else "_s16"))
-                if rec and rec.get("steps_per_launch", main_run.spl) == main_run.spl:
+                if rec and rec.get("steps_per_launch", main_run.spl) == main_run.spl and steps % main_run.spl == 0:
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -284,7 +286,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "adsp::fftconv_kernel", "avg_launch_us": round(per_launch_s * 1e6, 2),
-                         "launches": launches, "algorithmic_bytes_per_launch": alg_bytes * samples_per_launch},
+                         "launches": launches, "algorithmic_bytes_per_launch": int(alg_bytes * samples_per_launch)},
         }
         if extra_stream:
             line["stream"] = extra_stream
