@@ -226,6 +226,36 @@ ADSP_API int adsp_delay_apply_device(adsp_delay* line, const float* d_in, float*
 /* host buffers, synchronous (with accumulate on, `out` is read as well as written) */
 ADSP_API int adsp_delay_apply_host(adsp_delay* line, const float* in, float* out, int n_steps);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Per-channel sequential scans (last item): the reference's recursive devices.  One lane per channel,
+ * float32 [step][channel][sample] batches like everything else, state carried across calls, in-place allowed.
+ *   biquad cascade - EffectEQ3Band.py:95-181: every section is
+ *        y[i] = f32( c0 x[i-1] + c1 x[i-2] + c2 x[i-3] - c3 y[i-1] - c4 y[i-2] )        (float64, left to right)
+ *     with c = (b0, b1, b2, a1, a2) / a0; the one-sample input delay is the reference's (it prepends three old inputs
+ *     but two old outputs).  Sections run in series (applylowband -> applymidband -> applyhighband = 3 sections).
+ *   compressor - EffectCompressor.py:43-125: attack / hold / release state machine over two gain envelopes
+ *     (linspace(1, ratio, attack samples), linspace(ratio, 1, release samples)), threshold on |x|.
+ * ------------------------------------------------------------------------------------------------------------- */
+#define ADSP_SCAN_BIQUAD 1
+#define ADSP_SCAN_COMPRESSOR 2
+#define ADSP_SCAN_MAX_SECTIONS 4
+typedef struct adsp_scan adsp_scan; /* opaque */
+typedef struct adsp_scan_config {
+    int device_id;
+    int chunk_size;  /* any positive length */
+    int n_channels;
+    int kind;        /* set by the create functions */
+    int n_sections;  /* biquad cascade: 1..ADSP_SCAN_MAX_SECTIONS */
+} adsp_scan_config;
+/* coefficients: [n_sections][5] doubles b0/a0, b1/a0, b2/a0, a1/a0, a2/a0 */
+ADSP_API int adsp_scan_create_biquad(const adsp_scan_config* cfg, const double* coefficients, adsp_scan** out);
+ADSP_API int adsp_scan_create_compressor(const adsp_scan_config* cfg, float threshold, const float* attack_envelope,
+                                         int n_attack, const float* release_envelope, int n_release, adsp_scan** out);
+ADSP_API void adsp_scan_destroy(adsp_scan* scan);
+ADSP_API int adsp_scan_reset(adsp_scan* scan);
+ADSP_API int adsp_scan_apply_device(adsp_scan* scan, const float* d_in, float* d_out, int n_steps, void* stream);
+ADSP_API int adsp_scan_apply_host(adsp_scan* scan, const float* in, float* out, int n_steps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,11 @@ class AdspDelayConfig(ctypes.Structure):
                 ("n_taps", ctypes.c_int)]
 
 
+class AdspScanConfig(ctypes.Structure):
+    _fields_ = [("device_id", ctypes.c_int), ("chunk_size", ctypes.c_int), ("n_channels", ctypes.c_int),
+                ("kind", ctypes.c_int), ("n_sections", ctypes.c_int)]
+
+
 _c_int_p = ctypes.POINTER(ctypes.c_int)
 _c_float_p = ctypes.POINTER(ctypes.c_float)
 _engine_p = ctypes.c_void_p
@@ -65,6 +70,13 @@ SIGNATURES = {
     "adsp_mix_host": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
                                      ctypes.c_void_p, ctypes.c_size_t]),
     "adsp_set_accumulate": (ctypes.c_int, [_engine_p, ctypes.c_int]),
+    "adsp_scan_create_biquad": (ctypes.c_int, [ctypes.POINTER(AdspScanConfig), ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "adsp_scan_create_compressor": (ctypes.c_int, [ctypes.POINTER(AdspScanConfig), ctypes.c_float, ctypes.c_void_p, ctypes.c_int,
+                                                   ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "adsp_scan_destroy": (None, [ctypes.c_void_p]),
+    "adsp_scan_reset": (ctypes.c_int, [ctypes.c_void_p]),
+    "adsp_scan_apply_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "adsp_scan_apply_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "adsp_delay_create": (ctypes.c_int, [ctypes.POINTER(AdspDelayConfig), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float,
                                          ctypes.POINTER(ctypes.c_void_p)]),
     "adsp_delay_destroy": (None, [ctypes.c_void_p]),

@@ -1,0 +1,417 @@
+// adsp_scan.hip - the reference's recursive devices (last item): per-channel sequential scans.
+//
+//   * biquad cascade   EffectEQ3Band.py:95-181   y[i] = f32(c0 x[i-1] + c1 x[i-2] + c2 x[i-3] - c3 y[i-1] - c4 y[i-2])
+//   * compressor       EffectCompressor.py:43-125 attack / hold / release state machine over two gain envelopes
+//
+// Both carry state from one sample to the next, so time cannot be split across lanes without changing the rounding the
+// reference's loops produce.  What is parallel is the channel axis: ONE LANE PER CHANNEL, 64 channels per workgroup.
+// Memory stays coalesced through an LDS tile: the wave loads 64 channels x 64 samples row by row (256 contiguous bytes
+// per row), each lane then walks its own row (rows padded to 65 floats: conflict-free), and the tile is stored back row
+// by row.  Latency-bound by construction (a dependent chain of ~10 float64 operations per sample and section); the
+// numbers are in DESIGN.md section 6f.
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "../../include/adsp.h"
+#include "capi_common.hpp"
+
+using adsp::fail;
+
+namespace {
+
+constexpr int TILE = 64;
+
+struct ScanArgs {
+    const float* in;
+    float* out;
+    int C, N, n_steps;
+    // biquad
+    int n_sections;
+    const double* coef;  // [n_sections][5]: b0/a0, b1/a0, b2/a0, a1/a0, a2/a0
+    float* bq_state;     // [n_sections][5][C]: x[-3], x[-2], x[-1], y[-2], y[-1]
+    // compressor
+    float threshold;
+    const float* attack;
+    const float* release;
+    int x_max, y_max;
+    int* cp_state;  // [3][C]: x, y, state (0 resting, 1 attack, 2 release)
+    int env_in_lds;  // the two envelopes fit the dynamic LDS block: the per-sample gain lookup never leaves the CU
+};
+
+template <int NS>  // sections: compile-time so that coefficients and state live in registers
+struct Biquad {
+    double c[NS][5];
+    float xh[NS][3], yh[NS][2];
+    static constexpr int ns = NS;
+    __device__ void load(const ScanArgs& a, int ch) {
+#pragma unroll
+        for (int s = 0; s < ns; ++s) {
+            for (int k = 0; k < 5; ++k) c[s][k] = a.coef[s * 5 + k];
+            for (int k = 0; k < 3; ++k) xh[s][k] = a.bq_state[(static_cast<size_t>(s) * 5 + k) * a.C + ch];
+            for (int k = 0; k < 2; ++k) yh[s][k] = a.bq_state[(static_cast<size_t>(s) * 5 + 3 + k) * a.C + ch];
+        }
+    }
+    __device__ void save(const ScanArgs& a, int ch) const {
+#pragma unroll
+        for (int s = 0; s < ns; ++s) {
+            for (int k = 0; k < 3; ++k) a.bq_state[(static_cast<size_t>(s) * 5 + k) * a.C + ch] = xh[s][k];
+            for (int k = 0; k < 2; ++k) a.bq_state[(static_cast<size_t>(s) * 5 + 3 + k) * a.C + ch] = yh[s][k];
+        }
+    }
+    __device__ void stage_tables(const ScanArgs&, float*, int) {}
+    __device__ void begin_chunk() {}
+    // float64, left to right, every product and sum rounded on its own (no fma) - what numpy's scalar arithmetic does
+    __device__ float sample(float v) {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int s = 0; s < ns; ++s) {
+            const double acc = c[s][0] * static_cast<double>(xh[s][2]) + c[s][1] * static_cast<double>(xh[s][1]) +
+                               c[s][2] * static_cast<double>(xh[s][0]) - c[s][3] * static_cast<double>(yh[s][1]) -
+                               c[s][4] * static_cast<double>(yh[s][0]);
+            const float y = static_cast<float>(acc);
+            xh[s][0] = xh[s][1];
+            xh[s][1] = xh[s][2];
+            xh[s][2] = v;  // this sample is used from the next output on (the reference's one-sample input delay)
+            yh[s][0] = yh[s][1];
+            yh[s][1] = y;
+            v = y;
+        }
+        return v;
+    }
+};
+
+template <bool ENV_LDS>  // gain envelopes staged in LDS (typed pointer: ds_read, not a flat load) or left in global memory
+struct Compressor {
+    int x, y, state;
+    bool full, freeze;
+    int where;  // 0 top, 1 attack, 2 hold, 3 release - position in the reference's loop nest, restarts at every chunk
+    float threshold;
+    const float *attack, *release;
+    int x_max, y_max;
+    double ratio;
+    __device__ void load(const ScanArgs& a, int ch) {
+        x = a.cp_state[ch];
+        y = a.cp_state[a.C + ch];
+        state = a.cp_state[2 * a.C + ch];
+        threshold = a.threshold;
+        if constexpr (!ENV_LDS) {
+            attack = a.attack;
+            release = a.release;
+        }
+        x_max = a.x_max;
+        y_max = a.y_max;
+        ratio = static_cast<double>(x_max) / static_cast<double>(y_max);  // the reference's x_max / y_max, once
+    }
+    // every lane of the workgroup: copy the gain envelopes next to the tile (a gain lookup per sample from HBM/L2
+    // would put a memory round trip into the dependent chain)
+    __device__ void stage_tables(const ScanArgs& a, float* lds, int lane) {
+        if constexpr (ENV_LDS) {
+            for (int i = lane; i < a.x_max; i += TILE) lds[i] = a.attack[i];
+            for (int i = lane; i < a.y_max; i += TILE) lds[a.x_max + i] = a.release[i];
+            attack = lds;
+            release = lds + a.x_max;
+        }
+    }
+    __device__ void save(const ScanArgs& a, int ch) const {
+        a.cp_state[ch] = x;
+        a.cp_state[a.C + ch] = y;
+        a.cp_state[2 * a.C + ch] = state;
+    }
+    __device__ void begin_chunk() {
+        full = true;
+        freeze = false;
+        where = 0;
+    }
+    // One sample in, one sample out: the loop nest of EffectCompressor.py:67-124 advanced until it consumes the sample.
+    // At most seven positions are visited per sample (a chunk that starts inside a release with a loud sample: top ->
+    // attack -> hold -> release, interrupted -> top -> attack -> hold), so the walk
+    // is a fixed, predicated sequence: lanes of a wave sit at different positions and a data-dependent loop with
+    // early returns serialises them.  A sample that passes untouched is multiplied by 1.0f (exact).
+    __device__ float sample(float v) {
+        const bool above = fabsf(v) > threshold;
+        float gain = 1.0f;
+        bool done = false;
+        for (int visit = 0; visit < 8; ++visit) {
+            if (!__any(!done)) break;  // the whole wave has consumed its sample (usually after one or two visits)
+            if (done) continue;
+            if (where == 0) {
+                if (above || x != 0 || y != 0) {
+                    if (full && state == 0) {
+                        x = 0;
+                        state = 1;
+                    }
+                    if (!full && state == 2) {
+                        x = x_max - static_cast<int>(static_cast<double>(y) * ratio);
+                        freeze = false;
+                        state = 1;
+                    }
+                    where = 1;
+                } else {
+                    done = true;
+                }
+            } else if (where == 1) {
+                if (x < x_max && state == 1) {
+                    gain = attack[x++];
+                    done = true;
+                } else {
+                    where = 2;
+                }
+            } else if (where == 2) {
+                if (above && state == 1) {
+                    gain = attack[x_max - 1];
+                    done = true;
+                } else {
+                    state = 2;
+                    where = 3;
+                }
+            } else {
+                bool consumed = false;
+                if (y < y_max && state == 2) {
+                    x = 0;
+                    if (!above) {
+                        gain = release[y++];
+                        consumed = true;
+                    } else {
+                        full = false;
+                        y = 0;
+                        freeze = true;
+                    }
+                }
+                if (consumed) {
+                    done = true;
+                } else {
+                    if (y == y_max) {
+                        full = true;
+                        state = 0;
+                        x = 0;
+                        y = 0;
+                    }
+                    where = 0;
+                    done = !freeze;  // the sample after a completed release passes untouched
+                }
+            }
+        }
+        return v * gain;
+    }
+};
+
+// One wave = 64 channels.  Time is walked in tiles of 64 samples: while the lanes run the recurrence over tile t
+// (each lane its own LDS row), the 64 row loads of tile t+1 are already in flight into registers - the recurrence is a
+// long dependent chain, the loads are the only latency that can be hidden, and there is one wave per 64 channels to
+// hide it with.
+template <class Op>
+__global__ __launch_bounds__(TILE) void scan_kernel(const ScanArgs a) {
+    __shared__ float tile[TILE][TILE + 1];
+    const int lane = static_cast<int>(threadIdx.x);
+    const int c0 = static_cast<int>(blockIdx.x) * TILE;
+    const int ch = c0 + lane;
+    const bool mine = ch < a.C;
+    const int rows = a.C - c0 < TILE ? a.C - c0 : TILE;
+    const int tiles_per_chunk = (a.N + TILE - 1) / TILE;
+    const int n_tiles = a.n_steps * tiles_per_chunk;
+    extern __shared__ float dyn_lds[];
+    Op op;
+    if (mine) op.load(a, ch);
+    op.stage_tables(a, dyn_lds, lane);  // visible after the first __syncthreads below
+
+    // tile index -> (step, first sample); element (row r, column lane) of a tile
+    auto tile_base = [&](int t, int& w) -> size_t {
+        const int s = t / tiles_per_chunk, t0 = (t - s * tiles_per_chunk) * TILE;
+        w = a.N - t0 < TILE ? a.N - t0 : TILE;
+        return (static_cast<size_t>(s) * a.C + c0) * a.N + t0;
+    };
+    float pre[TILE];
+    auto fetch = [&](int t) {
+        int w;
+        const size_t base = tile_base(t, w);
+#pragma unroll
+        for (int r = 0; r < TILE; ++r) pre[r] = (r < rows && lane < w) ? a.in[base + static_cast<size_t>(r) * a.N + lane] : 0.f;
+    };
+    fetch(0);
+    for (int t = 0; t < n_tiles; ++t) {
+        int w;
+        const size_t base = tile_base(t, w);
+#pragma unroll
+        for (int r = 0; r < TILE; ++r) tile[r][lane] = pre[r];
+        __syncthreads();
+        if (t + 1 < n_tiles) fetch(t + 1);  // in flight during the recurrence below
+        if (mine) {
+            if (t % tiles_per_chunk == 0) op.begin_chunk();
+            for (int k = 0; k < w; ++k) tile[lane][k] = op.sample(tile[lane][k]);
+        }
+        __syncthreads();
+        if (lane < w)
+            for (int r = 0; r < rows; ++r) a.out[base + static_cast<size_t>(r) * a.N + lane] = tile[r][lane];
+        __syncthreads();
+    }
+    if (mine) op.save(a, ch);
+}
+
+}  // namespace
+
+struct adsp_scan {
+    adsp_scan_config cfg;
+    double* d_coef;
+    float* d_bq_state;
+    float *d_attack, *d_release;
+    int x_max, y_max;
+    float threshold;
+    int* d_cp_state;
+    float* stage;
+    size_t stage_elems;
+};
+
+namespace {
+int common_checks(const adsp_scan_config* cfg, adsp_scan** out) {
+    if (!cfg || !out) return fail(ADSP_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    if (cfg->chunk_size < 1) return fail(ADSP_ERR_ARG, "chunk_size must be positive");
+    if (cfg->n_channels < 1) return fail(ADSP_ERR_ARG, "n_channels must be positive");
+    int ndev = 0;
+    int rc = adsp_device_count(&ndev);
+    if (rc) return rc;
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(ADSP_ERR_ARG, "device_id %d out of range (%d devices)", cfg->device_id, ndev);
+    HIP_TRY(hipSetDevice(cfg->device_id));
+    return ADSP_OK;
+}
+adsp_scan* blank(const adsp_scan_config* cfg) {
+    adsp_scan* e = new adsp_scan();
+    e->cfg = *cfg;
+    e->d_coef = nullptr;
+    e->d_bq_state = nullptr;
+    e->d_attack = e->d_release = nullptr;
+    e->d_cp_state = nullptr;
+    e->stage = nullptr;
+    e->stage_elems = 0;
+    e->x_max = e->y_max = 0;
+    e->threshold = 0.f;
+    return e;
+}
+}  // namespace
+
+extern "C" {
+
+int adsp_scan_create_biquad(const adsp_scan_config* cfg, const double* coefficients, adsp_scan** out) {
+    int rc = common_checks(cfg, out);
+    if (rc) return rc;
+    if (!coefficients) return fail(ADSP_ERR_ARG, "NULL coefficients");
+    if (cfg->n_sections < 1 || cfg->n_sections > ADSP_SCAN_MAX_SECTIONS) return fail(ADSP_ERR_ARG, "n_sections %d: need 1..%d", cfg->n_sections, ADSP_SCAN_MAX_SECTIONS);
+    adsp_scan* e = blank(cfg);
+    e->cfg.kind = ADSP_SCAN_BIQUAD;
+    auto bail = [&](int code) {
+        adsp_scan_destroy(e);
+        return code;
+    };
+    const size_t nstate = (size_t)cfg->n_sections * 5 * cfg->n_channels;
+    hipError_t err;
+    if ((err = hipMalloc(&e->d_coef, (size_t)cfg->n_sections * 5 * sizeof(double))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
+    if ((err = hipMemcpy(e->d_coef, coefficients, (size_t)cfg->n_sections * 5 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(err)));
+    if ((err = hipMalloc(&e->d_bq_state, nstate * sizeof(float))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
+    if ((err = hipMemset(e->d_bq_state, 0, nstate * sizeof(float))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMemset: %s", hipGetErrorString(err)));
+    *out = e;
+    return ADSP_OK;
+}
+
+int adsp_scan_create_compressor(const adsp_scan_config* cfg, float threshold, const float* attack_envelope, int n_attack,
+                                const float* release_envelope, int n_release, adsp_scan** out) {
+    int rc = common_checks(cfg, out);
+    if (rc) return rc;
+    if (!attack_envelope || !release_envelope) return fail(ADSP_ERR_ARG, "NULL envelope");
+    if (n_attack < 1 || n_release < 1) return fail(ADSP_ERR_ARG, "envelopes need at least one sample each (the reference indexes attack[len - 1])");
+    adsp_scan* e = blank(cfg);
+    e->cfg.kind = ADSP_SCAN_COMPRESSOR;
+    e->threshold = threshold;
+    e->x_max = n_attack;
+    e->y_max = n_release;
+    auto bail = [&](int code) {
+        adsp_scan_destroy(e);
+        return code;
+    };
+    hipError_t err;
+    if ((err = hipMalloc(&e->d_attack, n_attack * sizeof(float))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
+    if ((err = hipMalloc(&e->d_release, n_release * sizeof(float))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
+    if ((err = hipMemcpy(e->d_attack, attack_envelope, n_attack * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(err)));
+    if ((err = hipMemcpy(e->d_release, release_envelope, n_release * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(err)));
+    if ((err = hipMalloc(&e->d_cp_state, (size_t)3 * cfg->n_channels * sizeof(int))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
+    if ((err = hipMemset(e->d_cp_state, 0, (size_t)3 * cfg->n_channels * sizeof(int))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMemset: %s", hipGetErrorString(err)));
+    *out = e;
+    return ADSP_OK;
+}
+
+void adsp_scan_destroy(adsp_scan* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device_id);
+    (void)hipDeviceSynchronize();
+    for (void* p : {(void*)e->d_coef, (void*)e->d_bq_state, (void*)e->d_attack, (void*)e->d_release, (void*)e->d_cp_state, (void*)e->stage})
+        if (p) (void)hipFree(p);
+    delete e;
+}
+
+int adsp_scan_reset(adsp_scan* e) {
+    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    HIP_TRY(hipSetDevice(e->cfg.device_id));
+    HIP_TRY(hipDeviceSynchronize());
+    if (e->d_bq_state) HIP_TRY(hipMemset(e->d_bq_state, 0, (size_t)e->cfg.n_sections * 5 * e->cfg.n_channels * sizeof(float)));
+    if (e->d_cp_state) HIP_TRY(hipMemset(e->d_cp_state, 0, (size_t)3 * e->cfg.n_channels * sizeof(int)));
+    return ADSP_OK;
+}
+
+int adsp_scan_apply_device(adsp_scan* e, const float* d_in, float* d_out, int n_steps, void* stream) {
+    if (!e || !d_in || !d_out) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (n_steps <= 0) return fail(ADSP_ERR_ARG, "n_steps must be positive");
+    HIP_TRY(hipSetDevice(e->cfg.device_id));
+    ScanArgs a{};
+    a.in = d_in;
+    a.out = d_out;
+    a.C = e->cfg.n_channels;
+    a.N = e->cfg.chunk_size;
+    a.n_steps = n_steps;
+    a.n_sections = e->cfg.n_sections;
+    a.coef = e->d_coef;
+    a.bq_state = e->d_bq_state;
+    a.threshold = e->threshold;
+    a.attack = e->d_attack;
+    a.release = e->d_release;
+    a.x_max = e->x_max;
+    a.y_max = e->y_max;
+    a.cp_state = e->d_cp_state;
+    const unsigned grid = (unsigned)((a.C + TILE - 1) / TILE);
+    const size_t env_bytes = ((size_t)e->x_max + (size_t)e->y_max) * sizeof(float);
+    a.env_in_lds = (e->cfg.kind == ADSP_SCAN_COMPRESSOR && env_bytes <= 40 * 1024) ? 1 : 0;
+    if (e->cfg.kind == ADSP_SCAN_BIQUAD) {
+        switch (e->cfg.n_sections) {
+            case 1: hipLaunchKernelGGL(scan_kernel<Biquad<1>>, dim3(grid), dim3(TILE), 0, (hipStream_t)stream, a); break;
+            case 2: hipLaunchKernelGGL(scan_kernel<Biquad<2>>, dim3(grid), dim3(TILE), 0, (hipStream_t)stream, a); break;
+            case 3: hipLaunchKernelGGL(scan_kernel<Biquad<3>>, dim3(grid), dim3(TILE), 0, (hipStream_t)stream, a); break;
+            default: hipLaunchKernelGGL(scan_kernel<Biquad<4>>, dim3(grid), dim3(TILE), 0, (hipStream_t)stream, a); break;
+        }
+    } else if (a.env_in_lds)
+        hipLaunchKernelGGL(scan_kernel<Compressor<true>>, dim3(grid), dim3(TILE), env_bytes, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(scan_kernel<Compressor<false>>, dim3(grid), dim3(TILE), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return ADSP_OK;
+}
+
+int adsp_scan_apply_host(adsp_scan* e, const float* in, float* out, int n_steps) {
+    if (!e || !in || !out) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (n_steps <= 0) return fail(ADSP_ERR_ARG, "n_steps must be positive");
+    HIP_TRY(hipSetDevice(e->cfg.device_id));
+    const size_t elems = (size_t)n_steps * e->cfg.n_channels * e->cfg.chunk_size;
+    if (elems > e->stage_elems) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (e->stage) (void)hipFree(e->stage);
+        e->stage = nullptr;
+        e->stage_elems = 0;
+        HIP_TRY(hipMalloc(&e->stage, elems * sizeof(float)));
+        e->stage_elems = elems;
+    }
+    HIP_TRY(hipMemcpy(e->stage, in, elems * sizeof(float), hipMemcpyHostToDevice));
+    int rc = adsp_scan_apply_device(e, e->stage, e->stage, n_steps, nullptr);  // in place
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, e->stage, elems * sizeof(float), hipMemcpyDeviceToHost));
+    return ADSP_OK;
+}
+
+}  // extern "C"

@@ -261,6 +261,31 @@ def main():
     dl["reverb256_800ms_48k"] = np.concatenate([rv.applyreverb(x[i * 256:(i + 1) * 256].copy()) for i in range(60)])
     save("kat_callers", **dl)
 
+    # ---- J: the recursive devices (last item): IIR 3-band EQ and the compressor --------------------
+    rc = {}
+    ref.config.initialize(44100, 1024)
+    x = stream(160, 6 * 1024)
+    eq = ref.CreateEQ3Band(100, 2, 700, -4, 8000, 5)
+    rc["iir_low"] = np.concatenate([eq.applylowband(x[i * 1024:(i + 1) * 1024].copy()) for i in range(6)])
+    rc["iir_mid"] = np.concatenate([eq.applymidband(x[i * 1024:(i + 1) * 1024].copy()) for i in range(6)])
+    rc["iir_high"] = np.concatenate([eq.applyhighband(x[i * 1024:(i + 1) * 1024].copy()) for i in range(6)])
+    eq = ref.CreateEQ3Band(250, -6, 1500, 3, 6000, -2.5)
+    rc["iir_cascade"] = np.concatenate([eq.applyhighband(eq.applymidband(eq.applylowband(x[i * 1024:(i + 1) * 1024].copy())))
+                                        for i in range(6)])
+    rc["iir_coeffs"] = np.array([eq.LOWb0, eq.LOWb1, eq.LOWb2, eq.LOWa0, eq.LOWa1, eq.LOWa2, eq.MIDb0, eq.MIDb1, eq.MIDb2, eq.MIDa0,
+                                 eq.MIDa1, eq.MIDa2, eq.HIGHb0, eq.HIGHb1, eq.HIGHb2, eq.HIGHa0, eq.HIGHa1, eq.HIGHa2])
+    # compressor: bursts around the threshold exercise attack / hold / release / re-trigger / chunk boundaries
+    rng = np.random.default_rng(161)
+    n = 1024
+    env = np.repeat(rng.choice([0.05, 0.12, 0.3, 0.9], size=12 * n // 64), 64).astype(np.float32)
+    xc = (rng.uniform(-1, 1, 12 * n).astype(np.float32) * env).astype(np.float32)
+    rc["comp_input"] = xc
+    for tag, kw in [("default", {}), ("fast", {"threshold_in_db": -20, "ratio": 0.3, "attack_in_ms": 0.5, "release_in_ms": 2.0}),
+                    ("slow", {"threshold_in_db": -10, "ratio": 0.8, "attack_in_ms": 10.0, "release_in_ms": 100.0})]:
+        cp = ref.CreateCompressor(**kw)
+        rc["comp_" + tag] = np.concatenate([cp.apply(xc[i * n:(i + 1) * n].copy()) for i in range(12)])
+    save("kat_recursive", **rc)
+
     with open(os.path.join(HERE, "META.txt"), "w") as fh:
         for k in sorted(meta):
             fh.write(f"{k} = {meta[k]}\n")

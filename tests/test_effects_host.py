@@ -56,3 +56,12 @@ def test_mix_signals_argument_errors(pkg):
         pkg.MixSignals()
     with pytest.raises(ValueError, match="equal in length"):
         pkg.MixSignals(np.zeros(4, np.float32), np.zeros(5, np.float32))
+
+
+def test_iir_coefficients_match_reference_without_gpu():
+    """recursive._rbj (host design, float64) against the coefficients captured from the reference."""
+    from conftest import load_golden
+    from pyaudiodsptools_amd.recursive import _rbj
+    want = load_golden("kat_recursive")["iir_coeffs"]
+    got = np.array(_rbj("lowshelf", 250, -6, 44100.0) + _rbj("peak", 1500, 3, 44100.0) + _rbj("highshelf", 6000, -2.5, 44100.0))
+    assert np.array_equal(got, want)
