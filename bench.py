@@ -13,7 +13,9 @@ channel batched as one grid; each 2N transform then keeps 1.5 N samples).  `--mo
 launch per step through the zero-copy ring (adsp_apply_ring), the real-time call pattern; its
 figure is also measured (after the timed region) and reported under "stream" in the same line.
 History is carried by the engine exactly as between reference apply() calls; every output sample of
-every step is produced inside the timed region.
+every step is produced inside the timed region.  Before the W warmup steps the same workload runs untimed for
+--prewarm-ms (default 300 ms): an idle MI355X needs tens of milliseconds of sustained load before its shader clock
+has ramped up, and a measurement that starts earlier reports the ramp, not the kernel.
 
 For N > 1 (torchrun, one rank per GPU) every rank owns its own channel shard (weak scaling); the
 only collective is the RCCL broadcast of the filter spectrum before the timed region.
@@ -45,15 +47,20 @@ FILTER_NAMES = {"lowcut": "CreateLowCutFilter(800)", "highcut": "CreateHighCutFi
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=1536)
+    ap.add_argument("--warmup", type=int, default=768)
+    ap.add_argument("--prewarm-ms", type=float, default=300.0,
+                    help="untimed run of the same workload before the W warmup steps, until this much wall time has passed: "
+                         "the shader clock of an idle MI355X takes tens of milliseconds of sustained load to ramp up "
+                         "(0.38 -> 0.47 of the roofline between a 1 ms and a 100 ms warm-up)")
     ap.add_argument("--channels", type=int, default=4096, help="channels PER GPU")
     ap.add_argument("--chunk", type=int, default=4096)
     ap.add_argument("--fs", type=int, default=44100)
     ap.add_argument("--filter", default="lowcut", choices=sorted(FILTER_NAMES))
     ap.add_argument("--mode", default="batch", choices=["batch", "offline", "stream"],
                     help="batch (= offline): --steps-per-launch steps per launch; stream: one launch per step, zero-copy ring")
-    ap.add_argument("--steps-per-launch", type=int, default=32)
+    ap.add_argument("--steps-per-launch", type=int, default=96,
+                    help="batch mode: chunks per channel per launch.  Multiples of 3 tile exactly (3 chunks = 2 blocks of 1.5 N kept samples)")
     ap.add_argument("--ring-slots", type=int, default=8)
     ap.add_argument("--fft-mult", type=int, default=0, help="force transform length = this multiple of the chunk (0 = smallest)")
     ap.add_argument("--io", default="f32", choices=["f32", "s16"],
@@ -177,9 +184,13 @@ class Runner:
                     eng.apply_device(self.ins[full % n_in][:rest], self.outs[full % 2][:rest], rest, sptr)
         self.run = run
 
-    def measure(self, steps, warm, barrier=None):
+    def measure(self, steps, warm, barrier=None, prewarm_ms=0.0):
         torch, eng = self.torch, self.eng
         steps = max(1, steps)
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < prewarm_ms:  # clock ramp: untimed, same workload
+            self.run(4 * self.spl)
+            torch.cuda.synchronize()
         self.run(warm)
         torch.cuda.synchronize()
         if barrier:
@@ -230,7 +241,7 @@ def main():
     C, N = args.channels, args.chunk
     alg_bytes = ALG_BYTES_PER_SAMPLE if args.io == "f32" else 4
     main_run = Runner(args, args.mode, fir, dev, local_rank, world, rank)
-    steps, warm, wall, kern_ms, launches = main_run.measure(args.steps, args.warmup, barrier)
+    steps, warm, wall, kern_ms, launches = main_run.measure(args.steps, args.warmup, barrier, args.prewarm_ms)
     if world > 1:
         t = torch.tensor([wall, kern_ms], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
@@ -241,7 +252,7 @@ def main():
         del main_run.ins
         torch.cuda.empty_cache()
         s_run = Runner(args, "stream", fir, dev, local_rank, world, rank)
-        s_steps, _, s_wall, s_kern_ms, s_launches = s_run.measure(128, 16)
+        s_steps, _, s_wall, s_kern_ms, s_launches = s_run.measure(2048, 512, None, args.prewarm_ms)
         s_per = s_kern_ms / 1e3 / s_launches
         extra_stream = {"value": round(C * N * s_steps / s_wall / 1e6, 1), "unit": "Msamples/s", "steps": s_steps,
                         "avg_kernel_us": round(s_per * 1e6, 2),
@@ -280,6 +291,7 @@ def main():
                     ("(library input ring)" if args.mode == "stream" else "([steps, channels, chunk] batches)"),
             "config": {"workload": f"{FILTER_NAMES[args.filter]}{'' if args.effect == 'none' else ' -> ' + args.effect} @ {args.fs} Hz, {C} mono channels x {N}-sample chunks per GPU",
                        "channels_per_gpu": C, "chunk_size": N, "mode": mode_key, "steps_per_launch": main_run.spl,
+                       "clock_ramp_prewarm_ms": args.prewarm_ms,
                        "fft_size": eng.geometry.fft_size, "spectrum": "real (zero-phase kernel)" if eng.real_spectrum else "complex",
                        "outputs_per_transform": (N if args.mode == "stream" else eng.block_outputs),
                        "parallelism": f"channel-shard x{world}"},
