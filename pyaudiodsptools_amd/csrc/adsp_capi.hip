@@ -181,6 +181,7 @@ struct adsp_engine {
     int lfo_len;      // tremolo: LFO table length and the reference's buffer length (EffectTremolo.py:40-45)
     long long lfo_copy_len;
     int epi_phase;
+    int epi_replay;
     const PlanInfo* plan_epi;  // twin of `plan` whose kernel applies the effect (nullptr: none available)
     bool epi_prepared;
     float epi_p[3];
@@ -312,6 +313,7 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
     a.accumulate = e->accumulate;
     a.real_spec = e->real_spec ? 1 : 0;
     a.epi_phase = e->epi_phase;
+    a.epi_replay = e->epi_replay;
     a.epi_op = e->epi_op;
     a.epi_p0 = e->epi_p[0];
     a.epi_p1 = e->epi_p[1];
@@ -430,6 +432,7 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     e->lfo_len = 0;
     e->lfo_copy_len = 0;
     e->epi_phase = 0;
+    e->epi_replay = 0;
     e->plan_epi = nullptr;
     e->epi_prepared = false;
     if (e->cfg.sample_format == ADSP_FORMAT_F32) {
@@ -578,6 +581,12 @@ int prepare_twin(adsp_engine* e) {
 int tremolo_run(adsp_engine* e, int max_steps, int* phase) {
     const long long N = e->cfg.chunk_size, L = e->lfo_len;
     long long len = e->lfo_copy_len;
+    e->epi_replay = 0;
+    if (len == N) {  // the buffer is stuck on one chunk's worth of table: this and every later chunk replay it
+        e->epi_replay = 1;
+        *phase = (int)((L - N % L) % L);
+        return max_steps;
+    }
     while (len < N) len += L;
     *phase = (int)((L - len % L) % L);
     int run = 0;
@@ -610,6 +619,7 @@ int adsp_set_epilogue(adsp_engine* e, int effect, float p0, float p1, float p2) 
     e->lfo_len = effect == ADSP_EFFECT_TREMOLO ? (int)p2 : 0;
     e->lfo_copy_len = e->lfo_len;  // a fresh LFO: one table in the buffer (EffectTremolo.py:24)
     e->epi_phase = 0;
+    e->epi_replay = 0;
     return ADSP_OK;
 }
 

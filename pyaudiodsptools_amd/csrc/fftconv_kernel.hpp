@@ -84,6 +84,7 @@ struct KernelArgs {
     int epi_op;            // fused output epilogue (0 = none), see apply_epilogue
     float epi_p0, epi_p1, epi_p2;
     int epi_phase;         // tremolo: LFO table index of this launch's output sample 0
+    int epi_replay;        // tremolo: the table index restarts at epi_phase with EVERY chunk (the reference's stuck buffer)
     int accumulate;        // 1: add the kept samples to what `out` holds (partitioned FIRs, mixing); 2: and clip the sum
                            // to [-1, 1] (MixSignals).  Plain kernels: generic geometry + mode 1 only; EPI kernels: all.
 };
@@ -910,6 +911,20 @@ template <int P, int T>
 __device__ __forceinline__ void tremolo_loop(float (&xr)[P], float (&xi)[P], const KernelArgs& a, int tau0) {
     const int len = static_cast<int>(a.epi_p2);
     const float inv_len = 1.f / a.epi_p2;
+    if (a.epi_replay) {
+        // every chunk replays the table from epi_phase: index = (phase + time within the chunk) mod len
+        const float inv_n = 1.f / static_cast<float>(a.N);
+        int r0 = tau0 % a.N;  // once per thread; negative for samples that are not kept
+        r0 += r0 < 0 ? a.N : 0;
+#pragma unroll
+        for (int m = 0; m < P; ++m) {
+            const int r = small_mod(r0 + 2 * T * m, a.N, inv_n);
+            const int r1 = r + 1 == a.N ? 0 : r + 1;
+            xr[m] *= tremolo_gain(small_mod(a.epi_phase + r, len, inv_len), a.epi_p0, a.epi_p1);
+            xi[m] *= tremolo_gain(small_mod(a.epi_phase + r1, len, inv_len), a.epi_p0, a.epi_p1);
+        }
+        return;
+    }
     int base = (a.epi_phase + tau0) % len;  // once per thread; tau0 may be negative for samples that are not kept
     base += base < 0 ? len : 0;
 #pragma unroll

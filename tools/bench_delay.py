@@ -21,7 +21,7 @@ ap.add_argument("--chunk", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=32)
 ap.add_argument("--ms", type=float, default=500)
 ap.add_argument("--loops", type=int, default=2)
-ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--reps", type=int, default=40)
 a = ap.parse_args()
 
 adsp.config.initialize(44100, a.chunk)
@@ -29,9 +29,11 @@ d = adsp.CreateDelay(a.ms, a.loops, channels=a.channels)
 x = torch.rand((a.steps, a.channels, a.chunk), device="cuda") * 2 - 1
 y = torch.empty_like(x)
 s = torch.cuda.current_stream().cuda_stream
-for _ in range(3):
+import time  # noqa: E402
+t_pre = time.perf_counter()
+while time.perf_counter() - t_pre < 0.3:  # clock ramp: sustained regime before timing
     d.line.apply_device(x, y, a.steps, s)
-torch.cuda.synchronize()
+    torch.cuda.synchronize()
 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 t0.record()
 for _ in range(a.reps):
