@@ -44,9 +44,9 @@
 #define ADSP_ABLATE 0
 #endif
 
-// ADSP_NT: bit 0 = non-temporal output stores, bit 1 = non-temporal input loads (tuning A/B)
+// ADSP_NT: bit 0 = non-temporal output stores, bit 1 = non-temporal input loads in multi-step launches
 #ifndef ADSP_NT
-#define ADSP_NT 1
+#define ADSP_NT 3
 #endif
 
 // ADSP_WIDE_IO: 1 = 16-byte global accesses + DPP lane-pair exchange, 0 = 8-byte accesses (tuning A/B)
@@ -643,28 +643,36 @@ __device__ __forceinline__ float lane_xor1(float v) {
 // `cb`/`ob` pointers passed in already carry the per-lane adjustment (+2T-2 floats on odd lanes).
 template <class PL, int FN, int RQ>
 __device__ __forceinline__ void load_window(const float* const (&cb)[FN + 1], float (&xr)[PL::P], float (&xi)[PL::P],
-                                            bool odd) {
+                                            bool odd, bool nt) {
     constexpr int P = PL::P, T = PL::T, MPC = P / FN, Q = MPC / 4;
     static_assert(MPC % 4 == 0, "need at least 4 registers per chunk");
     if constexpr (ADSP_WIDE_IO && Q % 2 == 0) {
         // All P/2 loads are issued before the first result is touched: left to itself the scheduler interleaves the
         // lane exchange of the first results with the address arithmetic of the last loads, which then leave one full
         // HBM round trip late.
+        // Multi-step launches stream their input once (the overlap of neighbouring blocks is found in L2 either way):
+        // non-temporal loads, +2 % measured.  Single-step launches re-read the history ring on the next call: plain loads.
         float4 v[P / 2];
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        if ((ADSP_NT & 2) && nt) {  // wave-uniform
 #pragma unroll
-        for (int u = 0; u < P / 2; ++u) {
-            const int gi = RQ * Q + 2 * u;  // registers 2u and 2u+1 are always in the same chunk
-            const int i = gi / MPC;
-            const int off = (gi % MPC) * 2 * T;
+            for (int u = 0; u < P / 2; ++u) {
+                const int gi = RQ * Q + 2 * u;  // registers 2u and 2u+1 are always in the same chunk
+                const v4f nv = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(cb[gi / MPC] + (gi % MPC) * 2 * T));
+                v[u] = make_float4(nv.x, nv.y, nv.z, nv.w);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < P / 2; ++u) {
+                const int gi = RQ * Q + 2 * u;
+                const int i = gi / MPC;
+                const int off = (gi % MPC) * 2 * T;
 #if ADSP_ABLATE & 8
-            v[u] = make_float4(static_cast<float>(off + i) * 1e-4f, reinterpret_cast<size_t>(cb[i]) * 1e-20f, 1.f, 2.f);
-#elif ADSP_NT & 2
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            const v4f nv = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(cb[i] + off));
-            v[u] = make_float4(nv.x, nv.y, nv.z, nv.w);
+                v[u] = make_float4(static_cast<float>(off + i) * 1e-4f, reinterpret_cast<size_t>(cb[i]) * 1e-20f, 1.f, 2.f);
 #else
-            v[u] = *reinterpret_cast<const float4*>(cb[i] + off);
+                v[u] = *reinterpret_cast<const float4*>(cb[i] + off);
 #endif
+            }
         }
 #if ADSP_LOAD_FENCE
         __builtin_amdgcn_sched_barrier(0);
@@ -1051,10 +1059,10 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(con
         }
     } else {
         switch ((t0 & (N - 1)) >> (LOGN - 2)) {
-            case 0: load_window<PL, FN, 0>(cb, xr, xi, odd); break;
-            case 1: load_window<PL, FN, 1>(cb, xr, xi, odd); break;
-            case 2: load_window<PL, FN, 2>(cb, xr, xi, odd); break;
-            default: load_window<PL, FN, 3>(cb, xr, xi, odd); break;
+            case 0: load_window<PL, FN, 0>(cb, xr, xi, odd, a.n_steps > 1); break;
+            case 1: load_window<PL, FN, 1>(cb, xr, xi, odd, a.n_steps > 1); break;
+            case 2: load_window<PL, FN, 2>(cb, xr, xi, odd, a.n_steps > 1); break;
+            default: load_window<PL, FN, 3>(cb, xr, xi, odd, a.n_steps > 1); break;
         }
     }
 
