@@ -52,7 +52,8 @@ typedef enum adsp_status {
     ADSP_ERR_NO_DEVICE = -4   /* no usable GPU */
 } adsp_status;
 
-typedef struct adsp_engine adsp_engine; /* opaque */
+typedef struct adsp_engine adsp_engine; /* opaque.  Engines (and delay lines, scans) are not internally locked: use one from
+                                           one thread at a time; different engines are independent. */
 
 /* Sample formats of the [step][channel][sample] batches an engine filters (adsp_config.sample_format). */
 #define ADSP_FORMAT_F32 0 /* float32, the reference's in-memory format */

@@ -88,6 +88,13 @@ class ShardedFirBank:
         except ImportError:
             pass
         self.spectrum_tensor, self.spectrum = broadcast_spectrum(spec, 0, bdev)
+        # the spectrum only means something with rank 0's window geometry: every rank must have derived the same one
+        mine = np.array([geo.fft_size, geo.history_chunks, geo.lookback, geo.out_offset, geo.shift, geo.max_block_outputs,
+                         int(geo.zero_phase)], dtype=np.float32)
+        _, theirs = broadcast_spectrum(mine, 0, bdev)
+        if not np.array_equal(mine, theirs):
+            raise ValueError(f"rank {rank}: filter geometry {mine.astype(int).tolist()} differs from rank 0's "
+                             f"{theirs.astype(int).tolist()} - every rank must be constructed with the same kind of filter")
         if engine_factory is None:
             from .engine import FirEngine
             engine_factory = FirEngine
