@@ -142,8 +142,8 @@ class CreateTremolo(Effect):
         return (self.tremolo_depth, self.lfo_in_hertz / self.sin_sample_rate, float(self.lfo_length))
 
     def _phase(self, n_samples):
-        while self._buffered < n_samples:
-            self._buffered += self.lfo_length
+        if self._buffered < n_samples:  # whole tables are appended until the buffer covers the chunk
+            self._buffered += -(-(n_samples - self._buffered) // self.lfo_length) * self.lfo_length
         phase = (-self._buffered) % self.lfo_length
         if self._buffered != n_samples:  # the reference's copy[-0:] keeps everything in that one case
             self._buffered -= n_samples
