@@ -170,6 +170,11 @@ def _generic_geometry(fir: FirStream, fft_mult: int, optimize_for: str) -> Geome
         raise ValueError(f"chunk_size {n}: need a multiple of 4 (>= 16)")
     if d_total <= 0:
         raise ValueError("non-causal stream")
+    centre = (m - 1) // 2
+    symmetric = m % 2 == 1 and np.abs(fir.taps - fir.taps[::-1]).max() <= 1e-13 * np.abs(fir.taps).max()
+    # a symmetric kernel centred on circular index 0 (real spectrum, see overlap_save_geometry) also needs less room
+    # in front of the kept slice: (m-1)/2 wrapped taps instead of m-1
+    zero_phase = bool(symmetric and (d_total + centre) % 4 == 0)
     best = None
     for log_f in range(7, 16):
         f = 1 << log_f
@@ -180,17 +185,22 @@ def _generic_geometry(fir: FirStream, fft_mult: int, optimize_for: str) -> Geome
             t2 = 4 * _capi.plan_describe(n, f)["threads_per_transform"]
         except _capi.AdspError:
             continue
-        j0 = -(-(m + 2) // t2) * t2
-        v = (f - j0) // t2 * t2
+        if zero_phase:
+            j0 = max(t2, -(-centre // t2) * t2)
+            v = (f - centre - j0) // t2 * t2
+            shift = -centre
+        else:
+            j0 = -(-(m + 2) // t2) * t2
+            v = (f - j0) // t2 * t2
+            shift = (d_total + j0) % 4
         if v < t2:
             continue
-        shift = (d_total + j0) % 4
         lookback = d_total + j0 - shift
         hist = -(-lookback // n)
         if hist > _capi.ADSP_MAX_HISTORY:
             continue
         cost = f * log_f / v
-        geo = Geometry(f, hist, lookback, j0, shift, v)
+        geo = Geometry(f, hist, lookback, j0, shift, v, zero_phase)
         if optimize_for == "stream":
             if v >= n:          # one block per call: smallest such transform wins
                 return geo
