@@ -1149,6 +1149,11 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_generic_ke
     const int t0 = o - a.lookback + a.nh * N;  // window start on the biased (>= 0) time axis: history chunk -nh is chunk 0
 
     float xr[P], xi[P];
+    // all loads first, then the lane exchanges (see load_window); non-temporal in multi-step launches
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    typename std::conditional<S16, v2u, v4f>::type raw[P / 2];
+    const bool nt = (ADSP_NT & 2) && a.n_steps > 1;
 #pragma unroll
     for (int u = 0; u < P / 2; ++u) {
         // even lane: elements (tid, tid+1) of register 2u; odd lane: elements (tid-1, tid) of register 2u+1
@@ -1169,12 +1174,24 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_generic_ke
             off += chan_units;
         }
         if constexpr (S16) {
-            const uint2 v = *reinterpret_cast<const uint2*>(base + off);
+            raw[u] = *reinterpret_cast<const v2u*>(base + off);
+        } else {
+            raw[u] = nt ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(base + off))
+                        : *reinterpret_cast<const v4f*>(base + off);
+        }
+    }
+#if ADSP_LOAD_FENCE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int u = 0; u < P / 2; ++u) {
+        if constexpr (S16) {
+            const v2u v = raw[u];
             const unsigned sx = lane_xor1_u(odd ? v.x : v.y);
             unpack_s16(odd ? sx : v.x, xr[2 * u], xi[2 * u]);
             unpack_s16(odd ? v.y : sx, xr[2 * u + 1], xi[2 * u + 1]);
         } else {
-            const float4 v = *reinterpret_cast<const float4*>(base + off);
+            const v4f v = raw[u];
             const float sx = lane_xor1(odd ? v.x : v.z), sy = lane_xor1(odd ? v.y : v.w);
             xr[2 * u] = odd ? sx : v.x;
             xi[2 * u] = odd ? sy : v.y;
