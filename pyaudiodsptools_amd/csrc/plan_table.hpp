@@ -76,7 +76,7 @@ constexpr PlanInfo make_plan() {
     make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 4, S16, EPI>(),              \
     make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1, 2, S16, EPI>(),                    \
     make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1, 4, S16, EPI>(),                    \
-    make_plan<Plan<16384, 32, 4, 32, 2, 16, 16>, 1, 4, S16, EPI>()
+    make_plan<Plan<16384, 32, 3, 32, 32, 16, 1>, 1, 4, S16, EPI>()
 
 // tables live in plans_f32.hip / plans_s16.hip (internal linkage there: host-only data, the device pass only
 // needs to see the instantiations)
