@@ -473,3 +473,38 @@ def test_soak_mixed_call_types_ring_wrap(adsp, n, kind):
     y = yd.cpu().numpy()
     for c in range(channels):
         assert_parity(y[:, c].reshape(-1), o.direct_stream_convolution(taps, x[:, c].reshape(-1), n), what=f"N={n} ch {c}")
+
+
+@pytest.mark.parametrize("n,m,lookahead,expect_real", [
+    (512, 255, 127, True),      # the reference's shape: delay + centre = N
+    (512, 129, 64, True),       # shorter symmetric kernel, delay + centre = 512
+    (512, 129, 60, False),      # symmetric, but delay + centre is no multiple of N/4: falls back to the complex stage
+    (1024, 511, 255, True),
+    (4096, 1001, 500, True),
+    (4096, 2047, 1023, True),
+    (1000, 499, 249, True),     # generic geometry: delay + centre = 1000, a multiple of 4
+    (1000, 499, 247, False),    # generic, delay + centre = 1002
+    (3000, 1499, 749, True),
+    (512, 254, 127, False),     # even length: no centre tap
+])
+def test_symmetric_kernels_take_the_real_spectrum_stage_and_match_direct_convolution(adsp, n, m, lookahead, expect_real):
+    """Arbitrary symmetric FIRs (not only the reference's windowed sincs): geometry choice and parity."""
+    from pyaudiodsptools_amd import FirStream
+    rng = np.random.default_rng(n + m)
+    half = rng.standard_normal((m + 1) // 2)
+    taps = np.concatenate([half, half[::-1][m % 2:]]) / m
+    assert len(taps) == m and np.array_equal(taps, taps[::-1])
+    fir = FirStream(taps, n, latency_chunks=1, lookahead=lookahead)
+    channels, steps = 3, 7
+    eng = adsp.FirEngine(fir, channels=channels, optimize_for="batch")
+    assert eng.geometry.zero_phase == expect_real and eng.real_spectrum == expect_real
+    x = seeded_stream(900 + n + m, steps * channels * n).reshape(steps, channels, n)
+    y = np.concatenate([eng.apply_host(x[:3]), eng.apply_host(x[3:4]), eng.apply_host(x[4:])])
+    for c in range(channels):
+        want = orc().direct_stream_convolution(taps, x[:, c].reshape(-1), n, 1, lookahead)
+        assert_parity(y[:, c].reshape(-1), want, what=f"N={n} m={m} ch {c}")
+    # an asymmetric kernel of the same length never takes it
+    skew = taps.copy()
+    skew[0] += 0.01
+    eng2 = adsp.FirEngine(FirStream(skew, n, 1, lookahead), channels=1)
+    assert not eng2.geometry.zero_phase and not eng2.real_spectrum
