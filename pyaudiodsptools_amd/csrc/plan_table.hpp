@@ -24,6 +24,9 @@ constexpr int lds_bytes() {
 #if ADSP_ABLATE & 1024
     if (PL::M == 4096) return 32000;
 #endif
+#if ADSP_ABLATE & 4096
+    if (PL::M == 4096) return 44 * 1024;  // tuning: three workgroups per CU instead of four
+#endif
     return PL::M * CPB * (int)sizeof(float2);
 }
 
