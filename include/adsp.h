@@ -147,6 +147,7 @@ ADSP_API int adsp_set_block_outputs(adsp_engine* engine, int block_outputs);
 #define ADSP_EFFECT_HARD_DISTORTION 3
 #define ADSP_EFFECT_SATURATOR 4
 #define ADSP_EFFECT_TREMOLO 5
+#define ADSP_EFFECT_BIT_CRUSHER 6 /* _EffectBitCrusher.py:8-12 (private in the reference): int16(trunc(32767 x)) // 512 / 64 */
 /* every later apply of a float32 engine returns effect(filter(x)); ADSP_EFFECT_NONE removes it */
 ADSP_API int adsp_set_epilogue(adsp_engine* engine, int effect, float p0, float p1, float p2);
 /* out[i] = effect(in[i]) on device / host float32 arrays of n values (in-place allowed).  phase = LFO table index of

@@ -46,6 +46,12 @@ def saturator(x, saturation_threshold_in_db=-20.0, makeup_gain=2.0, mode="hard")
     return (F(10 ** (makeup_gain / 20)) * np.where(x < 0, -a, a)).astype(F)
 
 
+def bit_crusher(x):
+    """_EffectBitCrusher.py:8-12 (private in the reference): 16-bit quantise, drop 9 bits with floor, rescale."""
+    q = (np.asarray(x, F) * 32767).astype(np.int16)
+    return (q // 512) / 64
+
+
 def volume_change(x, gain_change_in_db, overflow_protection=True):
     y = F(10 ** (gain_change_in_db / 20)) * np.asarray(x, F)
     return np.clip(y, F(-1), F(1)) if overflow_protection else y

@@ -10,6 +10,7 @@ ADSP_ABI_VERSION = 3
 ADSP_MAX_HISTORY = 8
 ADSP_FORMAT_F32, ADSP_FORMAT_S16 = 0, 1
 EFFECT_NONE, EFFECT_VOLUME, EFFECT_SOFT_CLIPPER, EFFECT_HARD_DISTORTION, EFFECT_SATURATOR, EFFECT_TREMOLO = 0, 1, 2, 3, 4, 5
+EFFECT_BIT_CRUSHER = 6
 ADSP_OK, ADSP_ERR_ARG, ADSP_ERR_HIP, ADSP_ERR_STATE, ADSP_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 
 

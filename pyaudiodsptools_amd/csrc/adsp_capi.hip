@@ -641,7 +641,7 @@ int tremolo_run(adsp_engine* e, int max_steps, int* phase) {
 
 int adsp_set_epilogue(adsp_engine* e, int effect, float p0, float p1, float p2) {
     if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
-    if (effect < ADSP_EFFECT_NONE || effect > ADSP_EFFECT_TREMOLO) return fail(ADSP_ERR_ARG, "unknown effect %d", effect);
+    if (effect < ADSP_EFFECT_NONE || effect > ADSP_EFFECT_BIT_CRUSHER) return fail(ADSP_ERR_ARG, "unknown effect %d", effect);
     if (effect != ADSP_EFFECT_NONE && e->cfg.sample_format != ADSP_FORMAT_F32)
         return fail(ADSP_ERR_ARG, "fused effects need a float32 engine");
     if (effect == ADSP_EFFECT_TREMOLO && !(p2 >= 1.f && p2 <= 8388608.f && p2 == (float)(int)p2))
@@ -664,7 +664,7 @@ int adsp_set_epilogue(adsp_engine* e, int effect, float p0, float p1, float p2) 
 namespace {
 int pointwise_launch(int device_id, int effect, float p0, float p1, float p2, int phase, const float* d_in, float* d_out,
                      size_t n, hipStream_t stream) {
-    if (effect < ADSP_EFFECT_NONE || effect > ADSP_EFFECT_TREMOLO) return fail(ADSP_ERR_ARG, "unknown effect %d", effect);
+    if (effect < ADSP_EFFECT_NONE || effect > ADSP_EFFECT_BIT_CRUSHER) return fail(ADSP_ERR_ARG, "unknown effect %d", effect);
     if (effect == ADSP_EFFECT_TREMOLO && (!(p2 >= 1.f && p2 <= 8388608.f) || phase < 0 || phase >= (int)p2))
         return fail(ADSP_ERR_ARG, "tremolo: p2 = table length (1..2^23), 0 <= phase < p2");
     HIP_TRY(hipSetDevice(device_id));

@@ -848,6 +848,7 @@ __device__ __forceinline__ void store_kept_s16(unsigned* const (&ob)[FN + 1], co
 //   3 CreateHardDistortion EffectHardDistortion.py:30-41  (0.8 + 0.2 sin((a - 0.8)/0.2)) sgn, with a = |x| if |x| <= 0.8
 //                       else sgn(x) (so x < -0.8 lands on sin(-9): the reference's asymmetry is kept)
 //   4 CreateSaturator   EffectSaturator.py:41-49    knee above p0, (p0+1)/2 above 1, makeup p1, mode p2 (1 hard, 2 soft)
+//   6 CreateBitCrusher  _EffectBitCrusher.py:8-12   int16(trunc(32767 x)) // 512 / 64 (private, unexported in the reference)
 //   5 CreateTremolo     EffectTremolo.py:19-47      periodic LFO table of p2 samples: gain = 1 - p0/2 + p0/2 sin(2 pi p1 n)
 // ------------------------------------------------------------------------------------------
 // One sample through effect OP (compile-time) - the reference's expressions in float32, with hardware log2/exp2/sin/rcp
@@ -877,6 +878,9 @@ __device__ __forceinline__ float effect_sample(float x, float p0, float p1, floa
         a = a > p0 ? knee : a;
         a = a > 1.f ? (p0 + 1.f) * 0.5f : a;
         return __builtin_copysignf(a, x) * p1;
+    } else if constexpr (OP == 6) {  // bit crusher: int16(trunc(32767 x)) floor-divided by 512, over 64
+        const int q = static_cast<int>(static_cast<short>(static_cast<int>(x * 32767.f)));  // astype('int16') wraps
+        return static_cast<float>(q >> 9) * 0.015625f;
     } else {
         return x;
     }
@@ -900,6 +904,7 @@ __device__ __forceinline__ float epilogue_value(float x, int op, float p0, float
         case 2: return effect_sample<2>(x, p0, p1, p2);
         case 3: return effect_sample<3>(x, p0, p1, p2);
         case 4: return effect_sample<4>(x, p0, p1, p2);
+        case 6: return effect_sample<6>(x, p0, p1, p2);
         default: return x;
     }
 }
@@ -953,6 +958,7 @@ __device__ __forceinline__ void apply_epilogue(float (&xr)[P], float (&xi)[P], c
         case 2: return epilogue_loop<2>(xr, xi, a);
         case 3: return epilogue_loop<3>(xr, xi, a);
         case 4: return epilogue_loop<4>(xr, xi, a);
+        case 6: return epilogue_loop<6>(xr, xi, a);
     }
 }
 

@@ -88,6 +88,16 @@ class CreateSaturator(Effect):
         return (self.saturation_coeff, 10 ** (self.makeup_gain / 20), float(self.mode))
 
 
+class CreateBitCrusher(Effect):
+    """The reference's private, unexported bit crusher (_EffectBitCrusher.py:3-12): 16-bit quantisation, the lowest 9 bits
+    dropped (floor), rescaled by 1/64 - so full scale comes out as +-1.0 in steps of 1/64.  float32 result (the reference
+    returns float64; every value is an exact multiple of 1/64 either way)."""
+    op = _capi.EFFECT_BIT_CRUSHER
+
+    def __init__(self):
+        self.placeholder = True
+
+
 class _Volume(Effect):
     op = _capi.EFFECT_VOLUME
 

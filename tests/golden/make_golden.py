@@ -191,6 +191,8 @@ def main():
     fx["saturator_soft"] = ref.CreateSaturator(-12.0, 3.0, 'soft').apply(loud)
     fx["volume_p6_clip"] = ref.VolumeChange(loud, 6.0)
     fx["volume_m35_noclip"] = ref.VolumeChange(loud, -3.5, False)
+    from pyAudioDspTools import _EffectBitCrusher as ref_crusher
+    fx["bitcrusher"] = ref_crusher.CreateBitCrusher().apply(stream(100, 4096))  # |x| <= 1: the int16 cast does not wrap
     ref.config.initialize(44100, 512)
     x = stream(101, 8 * 512)
     for tag, make in [("lowcut_softclip", lambda: (ref.CreateLowCutFilter(200), ref.CreateSoftClipper(0.44))),

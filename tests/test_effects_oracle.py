@@ -28,6 +28,13 @@ def test_effect_oracle_matches_reference(golden, name):
     assert np.abs(got.astype(np.float64) - want).max() <= 2.5e-7, name
 
 
+def test_bit_crusher_oracle_matches_reference(golden):
+    want = golden["kat_effects"]["bitcrusher"]
+    got = fx.bit_crusher(seeded_stream(100, 4096))
+    assert want.dtype == np.float64 and np.array_equal(got, want)
+    assert np.array_equal(want * 64, np.round(want * 64)) and np.abs(want).max() <= 1.0
+
+
 def test_hard_distortion_quirks_are_the_references(golden):
     """0 maps to +0.951 (not 0) and loud negative samples to -0.718 (not -0.968): documented reference behaviour."""
     y = fx.hard_distortion(np.array([0.0, 2.0, -2.0, 0.8, -0.8], np.float32))

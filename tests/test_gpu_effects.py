@@ -40,6 +40,21 @@ def test_standalone_effect_matches_reference_golden(adsp, golden, name):
     assert_parity(y, golden["kat_effects"][name], what=name)
 
 
+def test_bit_crusher_standalone_and_fused_is_exact(adsp, golden):
+    from pyaudiodsptools_amd.effects import CreateBitCrusher
+    x = seeded_stream(100, 4096)
+    y = CreateBitCrusher().apply(x)
+    assert y.dtype == np.float32 and np.array_equal(y, golden["kat_effects"]["bitcrusher"])
+    # fused behind a filter: exactly the crushed version of the plain filter output
+    adsp.config.initialize(44100, 512)
+    plain, fused = adsp.CreateLowCutFilter(200), adsp.CreateLowCutFilter(200)
+    fused.engine.set_epilogue(CreateBitCrusher())
+    from oracle import effects_oracle as fxo
+    for i in range(4):
+        chunk = x[i * 512:(i + 1) * 512] * np.float32(0.5)
+        assert np.array_equal(fused.apply(chunk), fxo.bit_crusher(plain.apply(chunk)).astype(np.float32))
+
+
 def test_standalone_effect_shapes_and_device_tensors(adsp):
     import torch
     from oracle import effects_oracle as fx
