@@ -237,9 +237,12 @@ ADSP_API int adsp_delay_apply_host(adsp_delay* line, const float* in, float* out
  *     but two old outputs).  Sections run in series (applylowband -> applymidband -> applyhighband = 3 sections).
  *   compressor - EffectCompressor.py:43-125: attack / hold / release state machine over two gain envelopes
  *     (linspace(1, ratio, attack samples), linspace(ratio, 1, release samples)), threshold on |x|.
+ *   gate - EffectGate.py:42-126: the same state machine over linspace(1, 1/depth) / linspace(1/depth, 1); the threshold
+ *     is tested on the raw sample and the sample is scaled by `depth` before the envelope: out = (x * depth) * env.
  * ------------------------------------------------------------------------------------------------------------- */
 #define ADSP_SCAN_BIQUAD 1
 #define ADSP_SCAN_COMPRESSOR 2
+#define ADSP_SCAN_GATE 3
 #define ADSP_SCAN_MAX_SECTIONS 4
 typedef struct adsp_scan adsp_scan; /* opaque */
 typedef struct adsp_scan_config {
@@ -253,6 +256,8 @@ typedef struct adsp_scan_config {
 ADSP_API int adsp_scan_create_biquad(const adsp_scan_config* cfg, const double* coefficients, adsp_scan** out);
 ADSP_API int adsp_scan_create_compressor(const adsp_scan_config* cfg, float threshold, const float* attack_envelope,
                                          int n_attack, const float* release_envelope, int n_release, adsp_scan** out);
+ADSP_API int adsp_scan_create_gate(const adsp_scan_config* cfg, float threshold, float depth, const float* attack_envelope,
+                                   int n_attack, const float* release_envelope, int n_release, adsp_scan** out);
 ADSP_API void adsp_scan_destroy(adsp_scan* scan);
 ADSP_API int adsp_scan_reset(adsp_scan* scan);
 ADSP_API int adsp_scan_apply_device(adsp_scan* scan, const float* d_in, float* d_out, int n_steps, void* stream);

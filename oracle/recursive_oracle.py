@@ -5,6 +5,7 @@ the reference by tests/golden/make_golden.py).
 Reference anchors:
   * EffectEQ3Band.py:31-93   RBJ-cookbook coefficients (Fs hard-wired to 44100), :95-181 the three per-sample loops
   * EffectCompressor.py:26-40 envelopes, :43-125 the attack / hold / release loop nest
+  * EffectGate.py:25-40 envelopes (sampling rate hard-wired to 44100), :42-126 the same loop nest on a depth-scaled copy
 
 Quirks restated on purpose:
   * every band is a biquad fed with the input delayed by ONE sample: the reference prepends three old input samples but
@@ -96,9 +97,13 @@ class OracleCompressor:
         self.x = self.y = 0
         self.state = RESTING
 
-    def apply(self, chunk):
+    def _prepare(self, chunk):
+        """(working copy, threshold mask) - EffectCompressor.py:57: the compressor works on the samples as they are."""
         v = np.array(chunk, F)
-        above = np.abs(v) > self.threshold
+        return v, np.abs(v) > self.threshold
+
+    def apply(self, chunk):
+        v, above = self._prepare(chunk)
         n, x_max, y_max = len(v), len(self.attack), len(self.release)
         full, freeze = True, False  # per-call locals in the reference
         i, where = 0, "top"
@@ -143,3 +148,22 @@ class OracleCompressor:
                     i += 1  # the sample after a completed release passes untouched
                 where = "top"
         return v
+
+
+class OracleGate(OracleCompressor):
+    """EffectGate.py:6-126: the compressor's loop nest (line for line the same, :61-124) run on `input * depth`
+    (:59, a fresh float32 array for float32 input), with the threshold mask taken from the UNSCALED input (:58) and
+    envelopes linspace(1, 1/depth) / linspace(1/depth, 1) at a hard-wired 44100 Hz (:29-33).  apply() returns the
+    scaled-and-shaped copy (:126); the caller's array is left alone."""
+
+    def __init__(self, threshold_in_db=-5, depth=0.1, attack=3.1, release=200.1):
+        self.depth = depth
+        self.threshold = F(10 ** (threshold_in_db / 20))
+        self.attack = np.linspace(1.0, 1.0 / depth, num=int((44100 / 1000) * attack), dtype=F)
+        self.release = np.linspace(1.0 / depth, 1.0, num=int((44100 / 1000) * release), dtype=F)
+        self.x = self.y = 0
+        self.state = RESTING
+
+    def _prepare(self, chunk):
+        raw = np.asarray(chunk, F)
+        return raw * self.depth, np.abs(raw) > self.threshold  # float32 array * Python float -> float32 (NEP 50)

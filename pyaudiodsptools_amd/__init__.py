@@ -16,7 +16,7 @@ from .devices import (CreateEQ3BandFFT, CreateEQ3BandFFTGPU, CreateHighCutFilter
 from .effects import (CreateHardDistortion, CreateSaturator, CreateSoftClipper, CreateTremolo, CreateVolumeChange,
                       Effect, MixSignals, VolumeChange)
 from .delay import CreateDelay, DelayLine
-from .recursive import CreateCompressor, CreateEQ3Band, ScanEngine
+from .recursive import CreateCompressor, CreateEQ3Band, CreateGate, ScanEngine
 from .engine import FirEngine, MixBus, PartitionedFirEngine, make_engine
 from . import wavio as Utility
 from .wavio import (CombineChunks, MakeChunks, MonoWavToNumpy16BitInt, MonoWavToNumpyFloat, NumpyFloatToWav,
@@ -26,5 +26,5 @@ __all__ = ["config", "CreateHighCutFilter", "CreateLowCutFilter", "CreateEQ3Band
            "CreateLowCutFilterGPU", "CreateEQ3BandFFTGPU", "FirEngine", "PartitionedFirEngine", "make_engine", "FirStream", "fuse", "Utility", "MakeChunks",
            "CombineChunks", "MonoWavToNumpyFloat", "MonoWavToNumpy16BitInt", "StereoWavToNumpyFloat", "NumpyFloatToWav",
            "WavBank", "CreateSoftClipper", "CreateHardDistortion", "CreateSaturator", "VolumeChange", "CreateVolumeChange",
-           "Effect", "CreateTremolo", "MixSignals", "MixBus", "CreateDelay", "DelayLine", "CreateEQ3Band", "CreateCompressor", "ScanEngine"]
+           "Effect", "CreateTremolo", "MixSignals", "MixBus", "CreateDelay", "DelayLine", "CreateEQ3Band", "CreateCompressor", "CreateGate", "ScanEngine"]
 __version__ = "0.1.0"

@@ -74,6 +74,8 @@ SIGNATURES = {
     "adsp_scan_create_biquad": (ctypes.c_int, [ctypes.POINTER(AdspScanConfig), ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
     "adsp_scan_create_compressor": (ctypes.c_int, [ctypes.POINTER(AdspScanConfig), ctypes.c_float, ctypes.c_void_p, ctypes.c_int,
                                                    ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "adsp_scan_create_gate": (ctypes.c_int, [ctypes.POINTER(AdspScanConfig), ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
+                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "adsp_scan_destroy": (None, [ctypes.c_void_p]),
     "adsp_scan_reset": (ctypes.c_int, [ctypes.c_void_p]),
     "adsp_scan_apply_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),

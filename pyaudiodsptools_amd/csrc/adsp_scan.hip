@@ -2,6 +2,8 @@
 //
 //   * biquad cascade   EffectEQ3Band.py:95-181   y[i] = f32(c0 x[i-1] + c1 x[i-2] + c2 x[i-3] - c3 y[i-1] - c4 y[i-2])
 //   * compressor       EffectCompressor.py:43-125 attack / hold / release state machine over two gain envelopes
+//   * gate             EffectGate.py:42-126       the same state machine; the threshold is tested on the raw sample, the
+//                                                 sample is scaled by `depth` first and the envelopes run 1 <-> 1/depth
 //
 // Both carry state from one sample to the next, so time cannot be split across lanes without changing the rounding the
 // reference's loops produce.  What is parallel is the channel axis: ONE LANE PER CHANNEL, 64 channels per workgroup.
@@ -32,6 +34,7 @@ struct ScanArgs {
     float* bq_state;     // [n_sections][5][C]: x[-3], x[-2], x[-1], y[-2], y[-1]
     // compressor
     float threshold;
+    float pre_gain;  // gate: the sample is scaled by `depth` before the envelope (EffectGate.py:59); compressor: 1
     const float* attack;
     const float* release;
     int x_max, y_max;
@@ -86,7 +89,7 @@ struct Compressor {
     int x, y, state;
     bool full, freeze;
     int where;  // 0 top, 1 attack, 2 hold, 3 release - position in the reference's loop nest, restarts at every chunk
-    float threshold;
+    float threshold, pre_gain;
     const float *attack, *release;
     int x_max, y_max;
     double ratio;
@@ -95,6 +98,7 @@ struct Compressor {
         y = a.cp_state[a.C + ch];
         state = a.cp_state[2 * a.C + ch];
         threshold = a.threshold;
+        pre_gain = a.pre_gain;
         if constexpr (!ENV_LDS) {
             attack = a.attack;
             release = a.release;
@@ -192,7 +196,9 @@ struct Compressor {
                 }
             }
         }
-        return v * gain;
+        // gate: (x * depth) * envelope, two float32 products like the reference's array multiply followed by the
+        // in-place element multiply; compressor: pre_gain = 1 (exact).  An untouched sample is multiplied by 1.0f.
+        return (v * pre_gain) * gain;
     }
 };
 
@@ -257,6 +263,7 @@ struct adsp_scan {
     float *d_attack, *d_release;
     int x_max, y_max;
     float threshold;
+    float pre_gain;
     int* d_cp_state;
     float* stage;
     size_t stage_elems;
@@ -286,6 +293,7 @@ adsp_scan* blank(const adsp_scan_config* cfg) {
     e->stage_elems = 0;
     e->x_max = e->y_max = 0;
     e->threshold = 0.f;
+    e->pre_gain = 1.f;
     return e;
 }
 }  // namespace
@@ -339,6 +347,16 @@ int adsp_scan_create_compressor(const adsp_scan_config* cfg, float threshold, co
     return ADSP_OK;
 }
 
+int adsp_scan_create_gate(const adsp_scan_config* cfg, float threshold, float depth, const float* attack_envelope,
+                          int n_attack, const float* release_envelope, int n_release, adsp_scan** out) {
+    if (!(depth > 0.f)) return fail(ADSP_ERR_ARG, "gate depth must be positive (the envelopes run to 1/depth)");
+    int rc = adsp_scan_create_compressor(cfg, threshold, attack_envelope, n_attack, release_envelope, n_release, out);
+    if (rc) return rc;
+    (*out)->cfg.kind = ADSP_SCAN_GATE;
+    (*out)->pre_gain = depth;
+    return ADSP_OK;
+}
+
 void adsp_scan_destroy(adsp_scan* e) {
     if (!e) return;
     (void)hipSetDevice(e->cfg.device_id);
@@ -371,6 +389,7 @@ int adsp_scan_apply_device(adsp_scan* e, const float* d_in, float* d_out, int n_
     a.coef = e->d_coef;
     a.bq_state = e->d_bq_state;
     a.threshold = e->threshold;
+    a.pre_gain = e->pre_gain;
     a.attack = e->d_attack;
     a.release = e->d_release;
     a.x_max = e->x_max;
@@ -378,7 +397,7 @@ int adsp_scan_apply_device(adsp_scan* e, const float* d_in, float* d_out, int n_
     a.cp_state = e->d_cp_state;
     const unsigned grid = (unsigned)((a.C + TILE - 1) / TILE);
     const size_t env_bytes = ((size_t)e->x_max + (size_t)e->y_max) * sizeof(float);
-    a.env_in_lds = (e->cfg.kind == ADSP_SCAN_COMPRESSOR && env_bytes <= 40 * 1024) ? 1 : 0;
+    a.env_in_lds = (e->cfg.kind != ADSP_SCAN_BIQUAD && env_bytes <= 40 * 1024) ? 1 : 0;
     if (e->cfg.kind == ADSP_SCAN_BIQUAD) {
         switch (e->cfg.n_sections) {
             case 1: hipLaunchKernelGGL(scan_kernel<Biquad<1>>, dim3(grid), dim3(TILE), 0, (hipStream_t)stream, a); break;

@@ -1,10 +1,7 @@
-"""The reference's recursive devices on the GPU (last item): CreateEQ3Band (IIR) and
-CreateCompressor.  Sample-to-sample recurrences cannot be split over time without changing their rounding, so libadsp
-runs them as per-channel sequential scans (one lane per channel, adsp_scan_*): the point of these classes is many
-channels per call (``channels=``, ``apply_batch``), and chains that stay on the device next to the FFT engines.
-
-CreateGate is not provided: the reference's ``apply`` works on a scaled copy and returns None (EffectGate.py:58-59, no
-return statement), so there is no behaviour to be equal to.
+"""The reference's recursive devices on the GPU (last item): CreateEQ3Band (IIR),
+CreateCompressor and CreateGate.  Sample-to-sample recurrences cannot be split over time without changing their rounding,
+so libadsp runs them as per-channel sequential scans (one lane per channel, adsp_scan_*): the point of these classes is
+many channels per call (``channels=``, ``apply_batch``), and chains that stay on the device next to the FFT engines.
 """
 import ctypes
 
@@ -39,6 +36,17 @@ class ScanEngine:
         h = ctypes.c_void_p(None)
         _capi.check(_capi.load().adsp_scan_create_compressor(ctypes.byref(cfg), float(threshold), _ptr(att), len(att), _ptr(rel),
                                                               len(rel), ctypes.byref(h)))
+        return cls(h, chunk_size, channels, device)
+
+    @classmethod
+    def gate(cls, threshold, depth, attack_envelope, release_envelope, chunk_size, channels=1, device=0):
+        """The compressor's state machine on (x * depth), threshold tested on the raw x (EffectGate.py:58-59)."""
+        att = np.ascontiguousarray(attack_envelope, dtype=np.float32)
+        rel = np.ascontiguousarray(release_envelope, dtype=np.float32)
+        cfg = _capi.AdspScanConfig(int(device), int(chunk_size), int(channels), 0, 0)
+        h = ctypes.c_void_p(None)
+        _capi.check(_capi.load().adsp_scan_create_gate(ctypes.byref(cfg), float(threshold), float(depth), _ptr(att), len(att),
+                                                        _ptr(rel), len(rel), ctypes.byref(h)))
         return cls(h, chunk_size, channels, device)
 
     def close(self):
@@ -170,6 +178,35 @@ class CreateCompressor:
             raise ValueError("attack and release must last at least one sample")
         self.engine = ScanEngine.compressor(self.threshold_power, self.attack_envelope, self.release_envelope, self._n,
                                             channels, device)
+
+    def apply(self, int_array_input):
+        return self.engine.apply_host(_one_chunk(int_array_input, self._n, self.channels)).reshape(self._n)
+
+    def apply_batch(self, x):
+        return self.engine.apply_host(x)
+
+    def reset(self):
+        self.engine.reset()
+
+
+class CreateGate:
+    """Drop-in for the reference's gate (EffectGate.py:6-126): same arguments, defaults and ``.apply(chunk)``.  The
+    reference scales a copy of the chunk by ``depth`` (:59), walks the compressor's attack / hold / release loop nest over
+    envelopes that run 1 -> 1/depth -> 1 (built for 44100 Hz whatever ``config`` says, :29-33), testing the threshold on
+    the unscaled samples (:58), and returns that copy (:126).  Bit for bit the same here for float32 chunks."""
+
+    def __init__(self, threshold_in_db=-5, depth=0.1, attack=3.1, release=200.1, *, channels=1, device=0):
+        if config.chunk_size is None:
+            raise RuntimeError("call config.initialize(sampling_rate, chunk_size) before creating devices")
+        self._n, self.channels = int(config.chunk_size), int(channels)
+        self.depth = depth
+        self.threshold_power = np.float32(10 ** (threshold_in_db / 20))
+        self.attack_envelope = np.linspace(1.0, 1.0 / depth, num=int((44100 / 1000) * attack), dtype="float32")
+        self.release_envelope = np.linspace(1.0 / depth, 1.0, num=int((44100 / 1000) * release), dtype="float32")
+        if len(self.attack_envelope) < 1 or len(self.release_envelope) < 1:
+            raise ValueError("attack and release must last at least one sample")
+        self.engine = ScanEngine.gate(self.threshold_power, np.float32(depth), self.attack_envelope, self.release_envelope,
+                                      self._n, channels, device)
 
     def apply(self, int_array_input):
         return self.engine.apply_host(_one_chunk(int_array_input, self._n, self.channels)).reshape(self._n)

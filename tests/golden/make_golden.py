@@ -39,7 +39,12 @@ def taps_of(spectrum, taps):
     return np.fft.ifft(spectrum).real[:taps].copy()
 
 
+ONLY = set(a for a in sys.argv[1:] if not a.startswith("-"))  # e.g. `make_golden.py kat_gate`: rewrite just that file
+
+
 def save(name, **arrays):
+    if ONLY and name not in ONLY:
+        return
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **arrays)
     print(f"{name}.npz  {os.path.getsize(path)} bytes")
@@ -287,6 +292,24 @@ def main():
         cp = ref.CreateCompressor(**kw)
         rc["comp_" + tag] = np.concatenate([cp.apply(xc[i * n:(i + 1) * n].copy()) for i in range(12)])
     save("kat_recursive", **rc)
+
+    # ---- K: the gate (EffectGate.py) - same state machine as the compressor on a depth-scaled copy, threshold on the raw
+    # input, sampling rate hard-wired to 44100.  Bursts around the three thresholds; the default release (8824 samples)
+    # spans many chunks.  The reference leaves its argument alone (it works on `input * depth`).
+    gt = {}
+    rng = np.random.default_rng(162)
+    n = 1024
+    env = np.repeat(rng.choice([0.04, 0.2, 0.5, 1.0], size=16 * n // 128), 128).astype(np.float32)
+    xg = (rng.uniform(-1, 1, 16 * n).astype(np.float32) * env).astype(np.float32)
+    gt["gate_input"] = xg
+    ref.config.initialize(48000, n)  # the gate ignores config: its envelopes are built for 44100 Hz whatever this says
+    for tag, kw in [("default", {}), ("fast", {"threshold_in_db": -12, "depth": 0.25, "attack": 0.5, "release": 3.0}),
+                    ("deep", {"threshold_in_db": -20, "depth": 0.01, "attack": 10.0, "release": 50.0})]:
+        g = ref.CreateGate(**kw)
+        keep = xg.copy()
+        gt["gate_" + tag] = np.concatenate([g.apply(xg[i * n:(i + 1) * n]) for i in range(16)])
+        assert np.array_equal(keep, xg) and gt["gate_" + tag].dtype == np.float32
+    save("kat_gate", **gt)
 
     with open(os.path.join(HERE, "META.txt"), "w") as fh:
         for k in sorted(meta):

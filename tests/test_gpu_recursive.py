@@ -105,6 +105,44 @@ def test_compressor_many_channels_against_oracle(adsp):
         adsp.CreateCompressor(attack_in_ms=0.0)
 
 
+GATE = {"default": {}, "fast": {"threshold_in_db": -12, "depth": 0.25, "attack": 0.5, "release": 3.0},
+        "deep": {"threshold_in_db": -20, "depth": 0.01, "attack": 10.0, "release": 50.0}}
+
+
+@pytest.mark.parametrize("tag", sorted(GATE))
+def test_gate_dropin_is_bit_exact(adsp, tag):
+    """EffectGate.py:42-126 (its apply DOES return the shaped copy, :126) against vectors captured from the reference."""
+    kat = load_golden("kat_gate")
+    n = 1024
+    adsp.config.initialize(48000, n)  # ignored by the gate like in the reference: envelopes are built for 44100 Hz
+    g = adsp.CreateGate(**GATE[tag])
+    x = kat["gate_input"]
+    keep = x.copy()
+    got = np.concatenate([g.apply(x[i * n:(i + 1) * n]) for i in range(16)])
+    assert got.dtype == np.float32 and np.array_equal(x, keep)       # fresh array, the argument is left alone
+    assert np.array_equal(got, kat["gate_" + tag]), int(np.argmax(got != kat["gate_" + tag]))
+    g.reset()
+    again = g.apply_batch(x.reshape(16, 1, n)).reshape(-1)
+    assert np.array_equal(again, kat["gate_" + tag])
+
+
+def test_gate_many_channels_against_oracle(adsp):
+    from oracle import recursive_oracle as ro
+    n, C, steps = 256, 67, 10
+    adsp.config.initialize(44100, n)
+    g = adsp.CreateGate(-9, 0.2, 1.0, 7.5, channels=C)
+    rng = np.random.default_rng(172)
+    env = np.repeat(rng.choice([0.03, 0.2, 0.5, 1.0], size=(steps * C * n) // 32), 32).astype(np.float32)
+    x = (rng.uniform(-1, 1, steps * C * n).astype(np.float32) * env).reshape(steps, C, n)
+    got = g.apply_batch(x)
+    for c in (0, 31, 63, 64, 66):
+        o = ro.OracleGate(-9, 0.2, 1.0, 7.5)
+        want = np.stack([o.apply(x[s, c]) for s in range(steps)])
+        assert np.array_equal(got[:, c], want), c
+    with pytest.raises(RuntimeError):
+        adsp.CreateGate(depth=-0.5)   # a non-positive depth is refused by the C ABI
+
+
 def test_scan_engine_argument_errors(adsp):
     from pyaudiodsptools_amd import ScanEngine
     with pytest.raises(RuntimeError):

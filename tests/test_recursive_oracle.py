@@ -48,3 +48,23 @@ def test_compressor_is_bit_exact(kat, tag):
     want = kat["comp_" + tag]
     assert np.array_equal(got, want), int(np.argmax(got != want))
     assert (want != x).mean() > 0.2  # the compressor actually worked on this input
+
+
+GATE = {"default": {}, "fast": {"threshold_in_db": -12, "depth": 0.25, "attack": 0.5, "release": 3.0},
+        "deep": {"threshold_in_db": -20, "depth": 0.01, "attack": 10.0, "release": 50.0}}
+
+
+@pytest.mark.parametrize("tag", sorted(GATE))
+def test_gate_is_bit_exact(tag):
+    """EffectGate.py:42-126 returns the depth-scaled, envelope-shaped copy (its last line is `return int_array_input`)."""
+    kat = load_golden("kat_gate")
+    n = 1024
+    x = kat["gate_input"]
+    keep = x.copy()
+    g = ro.OracleGate(**GATE[tag])
+    got = np.concatenate([g.apply(x[i * n:(i + 1) * n]) for i in range(16)])
+    want = kat["gate_" + tag]
+    assert got.dtype == np.float32 and np.array_equal(got, want), int(np.argmax(got != want))
+    assert np.array_equal(x, keep)
+    # the gate did something besides the plain depth scaling (opened on the loud bursts)
+    assert (want != x * np.float32(GATE[tag].get("depth", 0.1))).mean() > 0.2
