@@ -6,24 +6,28 @@
 Workload (BASELINE.json configs[1]): CreateLowCutFilter(800) @ 44.1 kHz on 4096 mono channels x
 4096-sample chunks per GPU, float32, synthetic uniform(-1,1) input already resident in HBM.
 
-A "step" filters one [channels, chunk] batch (one chunk per channel = one reference apply() per
-device).  Default mode "batch": the K steps' inputs sit in HBM as [steps, channels, chunk] arrays
-and are handed to adsp_apply_device `--steps-per-launch` steps at a time (many chunks of every
-channel batched as one grid; each 2N transform then keeps 1.5 N samples).  `--mode stream` runs one
-launch per step through the zero-copy ring (adsp_apply_ring), the real-time call pattern; its
-figure is also measured (after the timed region) and reported under "stream" in the same line.
-History is carried by the engine exactly as between reference apply() calls; every output sample of
-every step is produced inside the timed region.  Before the W warmup steps the same workload runs untimed for
---prewarm-ms (default 300 ms): an idle MI355X needs tens of milliseconds of sustained load before its shader clock
-has ramped up, and a measurement that starts earlier reports the ramp, not the kernel.
+A "step" is ONE PASS OF THE HOT PATH OVER ONE RESIDENT BATCH.  Default mode "batch": a batch is
+[chunks_per_step = 96, channels, chunk] float32 (6.4 GB in + 6.4 GB out at the default shape: many chunks of every
+channel batched as one grid, each 2N transform keeping 1.5 N samples) and a step is one adsp_apply_device launch over
+it; K steps = K launches over distinct resident batches.  (Round 1 counted single chunks as steps; the driver's
+`--steps 20` then timed a 0.8 ms region made of one ragged launch.  A step that is a whole batch makes the figure
+independent of K: 16 steps by default, 20 when the driver says so.)  `--mode stream` runs one launch per step over a
+[channels, chunk] batch through the zero-copy ring (adsp_apply_ring), the real-time call pattern; its figure is also
+measured (after the timed region) and reported under "stream" in the same line, launch by launch and replayed as a
+hipGraph.  History is carried by the engine exactly as between reference apply() calls; every output sample of every
+step is produced inside the timed region.  Before the W warmup steps the same workload runs untimed for --prewarm-ms
+(default 300 ms): an idle MI355X needs tens of milliseconds of sustained load before its shader clock has ramped up.
 
-For N > 1 (torchrun, one rank per GPU) every rank owns its own channel shard (weak scaling); the
-only collective is the RCCL broadcast of the filter spectrum before the timed region.
+For N > 1 (torchrun, one rank per GPU) every rank owns its own channel shard (weak scaling); the only collective is the
+RCCL broadcast of the filter spectrum before the timed region.
 
 Prints ONE JSON line on rank 0 (driver contract) including
-  roofline     - algorithmic bytes (8 B/sample) / average KERNEL duration (HIP events around each
-                 kernel launch on the launch stream, adsp_kernel_time) vs the 8 TB/s HBM3E spec
-  cpu_baseline - the oracle's literal restatement of the reference (numpy, 1 core), bounded sample.
+  roofline     - algorithmic bytes (8 B/sample) / average KERNEL duration (HIP events around each kernel launch on the
+                 launch stream, adsp_kernel_time) vs the 8 TB/s HBM3E spec; traffic from profiles/traffic.json (PMC)
+  latency      - config 3 (CreateEQ3BandFFT, 2048 stereo pairs x 512 samples) us per step in the real-time call
+                 pattern, and the numpy-API .apply(chunk) us per call (PCIe / launch bound; never `value`)
+  cpu_baseline - the oracle's restatement of the reference (numpy) on the host cores: literal 3N complex and 2N real
+                 variants, one process and one process per physical core; bounded sample.
 """
 import argparse
 import json
@@ -44,11 +48,11 @@ FILTER_NAMES = {"lowcut": "CreateLowCutFilter(800)", "highcut": "CreateHighCutFi
                 "chain": "LowCut(800)->EQ3BandFFT(100,2,700,-4,8000,5)->HighCut(8000) fused"}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1536)
-    ap.add_argument("--warmup", type=int, default=768)
+    ap.add_argument("--steps", type=int, default=16, help="timed steps; a step = one launch over one resident batch (see module doc)")
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed run of the same workload before the W warmup steps, until this much wall time has passed: "
                          "the shader clock of an idle MI355X takes tens of milliseconds of sustained load to ramp up "
@@ -58,19 +62,25 @@ def parse():
     ap.add_argument("--fs", type=int, default=44100)
     ap.add_argument("--filter", default="lowcut", choices=sorted(FILTER_NAMES))
     ap.add_argument("--mode", default="batch", choices=["batch", "offline", "stream"],
-                    help="batch (= offline): --steps-per-launch steps per launch; stream: one launch per step, zero-copy ring")
-    ap.add_argument("--steps-per-launch", type=int, default=96,
-                    help="batch mode: chunks per channel per launch.  Multiples of 3 tile exactly (3 chunks = 2 blocks of 1.5 N kept samples)")
-    ap.add_argument("--ring-slots", type=int, default=4, help="stream mode: input ring length (the library default, 2 x history; fewer slots stay in the 256 MB Infinity Cache: 48 vs 51 us per step at 8)")
+                    help="batch (= offline): a step is one launch over [chunks-per-step, channels, chunk]; "
+                         "stream: a step is one launch over [channels, chunk] through the zero-copy ring")
+    ap.add_argument("--chunks-per-step", "--steps-per-launch", dest="chunks_per_step", type=int, default=0,
+                    help="batch mode: chunks per channel in one resident batch = per launch (0 = 96, rounded up to whole "
+                         "transform tiles: 3 chunks = 2 blocks of 1.5 N kept samples for the cut filters)")
+    ap.add_argument("--ring-slots", type=int, default=0, help="stream mode: input ring length (0 = history + 1, the smallest; "
+                    "3 slots x 64 MiB stay inside the 256 MB Infinity Cache at the default shape)")
     ap.add_argument("--fft-mult", type=int, default=0, help="force transform length = this multiple of the chunk (0 = smallest)")
     ap.add_argument("--io", default="f32", choices=["f32", "s16"],
                     help="sample format of the resident batches: float32 (headline) or int16 PCM (fused WAV front end, 4 B/sample)")
     ap.add_argument("--effect", default="none", choices=["none", "softclip", "harddist", "saturator", "volume", "tremolo"],
                     help="fuse a stateless wave-shaper on the kernel's output (not part of the headline workload)")
+    ap.add_argument("--trim", type=float, default=-1.0, help="chain only: end-tap trimming (FirStream.trimmed); -1 = library default, 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stream-extra", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    a = ap.parse_args()
+    ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="stream mode: do not try the hipGraph replay")
+    ap.add_argument("--cpu-seconds", type=float, default=5.0, help="per CPU-baseline measurement (four of them)")
+    a = ap.parse_args(argv)
     if a.mode == "offline":
         a.mode = "batch"
     return a
@@ -82,58 +92,42 @@ def make_fir(args):
     lc = design.FirStream(design.lowcut_kernel(800, fs, n), n)
     hc = design.FirStream(design.highcut_kernel(8000, fs, n), n)
     eq = design.FirStream(design.eq3_composite(100, 2, 700, -4, 8000, 5, fs, n), n)
-    return {"lowcut": lc, "highcut": hc, "eq3": eq, "chain": lc.then(eq).then(hc)}[args.filter]
+    if args.filter == "chain":  # what pyaudiodsptools_amd.fuse(lowcut, eq3, highcut) builds
+        ch = lc.then(eq).then(hc)
+        return ch if args.trim == 0 else ch.trimmed(design.TRIM_EPS if args.trim < 0 else args.trim)
+    return {"lowcut": lc, "highcut": hc, "eq3": eq}[args.filter]
 
 
 def cpu_baseline(args):
-    """ModuleTests.py:168-178 style timing of the reference's algorithm (oracle port), one core."""
-    from oracle import fftfilter_oracle as orc
-    n, fs = args.chunk, args.fs
-    if args.filter == "lowcut":
-        dev = orc.OracleLowCut(800, fs, n)
-    elif args.filter == "highcut":
-        dev = orc.OracleHighCut(8000, fs, n)
-    elif args.filter == "eq3":
-        dev = orc.OracleEQ3BandFFT(100, 2, 700, -4, 8000, 5, fs, n)
-    else:
-        a, b, c = (orc.OracleLowCut(800, fs, n), orc.OracleEQ3BandFFT(100, 2, 700, -4, 8000, 5, fs, n),
-                   orc.OracleHighCut(8000, fs, n))
-
-        class _Chain:
-            def apply(self, x):
-                return c.apply(b.apply(a.apply(x)))
-        dev = _Chain()
-    rng = np.random.default_rng(1234)
-    chunks = [rng.uniform(-1, 1, n).astype(np.float32) for _ in range(64)]
-    for ch in chunks[:8]:
-        dev.apply(ch)
-    done = 0
-    t0 = time.perf_counter()
-    while True:
-        for ch in chunks:
-            dev.apply(ch)
-        done += len(chunks)
-        el = time.perf_counter() - t0
-        if el >= args.cpu_seconds:
-            break
-    return {"value": round(done * n / el / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": f"1 channel x {done} chunks of {n} samples, numpy {np.__version__} literal 3N complex fft/ifft "
-                      f"(oracle restatement of the reference's apply), {el:.1f} s on 1 of {os.cpu_count()} host cores"}
+    """ModuleTests.py:168-178 style timing of the reference's algorithm (oracle port) on this box's host cores."""
+    from oracle import cpu_bench
+    m = cpu_bench.measure(args.filter, args.chunk, args.fs, seconds_each=args.cpu_seconds)
+    cores = m["physical_cores"]
+    return {"value": m["literal3n_allcores"], "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle restatement of the reference's apply (literal 3N complex fft/ifft, numpy {m['numpy']}), one process per "
+                      f"physical core over disjoint channels, {args.cpu_seconds:.0f} s per process, chunks of {args.chunk} samples; "
+                      f"{m['cpu_model']}, {cores} physical cores / {m['logical_cpus']} logical",
+            "variants_msamples_s": {"literal_3n_complex_1_process": m["literal3n_1proc"],
+                                    f"literal_3n_complex_{cores}_processes": m["literal3n_allcores"],
+                                    "rfft_2n_1_process_16ch_batches": m["rfft2n_1proc"],
+                                    f"rfft_2n_{cores}_processes_16ch_batches": m["rfft2n_allcores"]}}
 
 
 class Runner:
     """One measured configuration: engine + resident synthetic data + a run(k_steps) closure."""
 
-    def __init__(self, args, mode, fir, dev, local_rank, world, rank):
+    def __init__(self, args, mode, fir, dev, local_rank, world, rank, channels=None, chunk=None):
         import torch
         from pyaudiodsptools_amd import dist as adist
         self.torch = torch
         self.mode = mode
-        C, N = args.channels, args.chunk
+        C, N = channels or args.channels, chunk or args.chunk
         self.C, self.N = C, N
         stream_mode = mode == "stream"
-        self.bank = adist.ShardedFirBank(fir, C * world, device=local_rank,
-                                         ring_slots=args.ring_slots if stream_mode else 0, fft_mult=args.fft_mult,
+        from pyaudiodsptools_amd import design
+        geo = design.overlap_save_geometry(fir, args.fft_mult, "stream" if stream_mode else "batch")
+        slots = (args.ring_slots or geo.history_chunks + 1) if stream_mode else 0
+        self.bank = adist.ShardedFirBank(fir, C * world, device=local_rank, ring_slots=slots, fft_mult=args.fft_mult,
                                          sample_format=args.io, optimize_for="stream" if stream_mode else "batch")
         self.eng = eng = self.bank.engine
         assert eng.channels == C
@@ -150,6 +144,7 @@ class Runner:
         amp = float(os.environ.get("ADSP_BENCH_AMPLITUDE", "1"))  # tuning only: 0 = all-zero data (DVFS check)
         s16 = args.io == "s16"
         dt = torch.int16 if s16 else torch.float32
+        self.graph = None
 
         def synth(shape):
             if s16:  # uniform 16-bit PCM at -6 dBFS
@@ -164,41 +159,80 @@ class Runner:
                 eng.apply_device(batch, scratch, 1, sptr)
                 torch.cuda.synchronize(dev)
             self.outs = [torch.empty((C, N), device=dev, dtype=dt) for _ in range(4)]
-            self.spl = 1
+            self.cps = 1
+            self.samples_per_step = C * N
+
+            def run(k_steps, sp=sptr):
+                for i in range(k_steps):
+                    eng.apply_ring(self.outs[i % 4], sp)
+            self._launch_steps = run
+            self.graph_steps = 0
+            if not args.no_graph:
+                self._try_graph(12 * eng.ring_slots)
+
+            def run_any(k_steps):
+                if self.graph is not None and k_steps % self.graph_steps == 0:
+                    for _ in range(k_steps // self.graph_steps):
+                        self.graph.replay()
+                else:
+                    run(k_steps)
+            self.run = run
+            self.run_graph = run_any
+        else:
+            # whole transform tiles per launch: lcm(chunk, block_outputs) / chunk chunks tile exactly
+            tile = int(np.lcm(N, eng.block_outputs) // N)
+            cps = args.chunks_per_step or 96
+            self.cps = cps = -(-cps // tile) * tile
+            self.samples_per_step = cps * C * N
+            # distinct resident input batches, > 256 MiB in total so the Infinity Cache cannot hold them
+            n_in = max(2, min(8, -(-(768 << 20) // (cps * C * N * 4))))
+            self.ins = [synth((cps, C, N)) for _ in range(n_in)]
+            self.outs = [torch.empty((cps, C, N), device=dev, dtype=dt) for _ in range(2)]
 
             def run(k_steps):
                 for i in range(k_steps):
-                    eng.apply_ring(self.outs[i % 4], sptr)
-        else:
-            self.spl = spl = args.steps_per_launch
-            # distinct resident input batches, > 256 MiB in total so the Infinity Cache cannot hold them
-            n_in = max(2, min(8, -(-(768 << 20) // (spl * C * N * 4))))
-            self.ins = [synth((spl, C, N)) for _ in range(n_in)]
-            self.outs = [torch.empty((spl, C, N), device=dev, dtype=dt) for _ in range(2)]
+                    eng.apply_device(self.ins[i % n_in], self.outs[i % 2], cps, sptr)
+            self.run = run
 
-            def run(k_steps):
-                full, rest = divmod(k_steps, spl)
-                for i in range(full):
-                    eng.apply_device(self.ins[i % n_in], self.outs[i % 2], spl, sptr)
-                if rest:  # exactly k_steps: one shorter launch at the end
-                    eng.apply_device(self.ins[full % n_in][:rest], self.outs[full % 2][:rest], rest, sptr)
-        self.run = run
+    def _try_graph(self, steps_per_replay):
+        """Capture `steps_per_replay` consecutive single-step launches (a multiple of the ring length, so the ring
+        position is back where it started) into one hipGraph: same kernels, same arguments, no per-launch host cost."""
+        torch = self.torch
+        try:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            with torch.cuda.graph(g, stream=side):
+                self._launch_steps(steps_per_replay, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            self.graph, self.graph_steps = g, steps_per_replay
+        except Exception as exc:  # capture not possible on this stack: the launch-by-launch figure stands alone
+            self.graph, self.graph_steps, self.graph_error = None, 0, f"{type(exc).__name__}: {exc}"[:200]
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
 
-    def measure(self, steps, warm, barrier=None, prewarm_ms=0.0, time_kernels=True):
+    def measure(self, steps, warm, barrier=None, prewarm_ms=0.0, time_kernels=True, graph=False):
         torch, eng = self.torch, self.eng
+        run = self.run_graph if graph else self.run
         steps = max(1, steps)
         t_pre = time.perf_counter()
+        unit = self.graph_steps if graph else (4 if self.mode == "stream" else 1)
         while (time.perf_counter() - t_pre) * 1e3 < prewarm_ms:  # clock ramp: untimed, same workload
-            self.run(4 * self.spl)
+            run(unit)
             torch.cuda.synchronize()
-        self.run(warm)
+        if warm:
+            run(warm)
         torch.cuda.synchronize()
         if barrier:
             barrier()
         torch.cuda.synchronize()
-        eng.enable_kernel_timing(time_kernels)
+        eng.enable_kernel_timing(time_kernels and not graph)
         t0 = time.perf_counter()
-        self.run(steps)
+        run(steps)
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         if barrier:
@@ -209,6 +243,49 @@ class Runner:
         chk = self.outs[0].reshape(-1)[:: max(1, self.outs[0].numel() // 65536)].float()
         assert bool(torch.isfinite(chk).all()) and (float(chk.abs().max()) > 0 or os.environ.get("ADSP_BENCH_AMPLITUDE") == "0")
         return steps, warm, wall, kern_ms, launches
+
+
+def stream_figures(args, fir, dev, local_rank, world, rank, alg_bytes, channels=None, chunk=None, steps=2048):
+    """The real-time call pattern: one launch per [channels, chunk] batch through the zero-copy ring."""
+    import torch
+    r = Runner(args, "stream", fir, dev, local_rank, world, rank, channels, chunk)
+    C, N = r.C, r.N
+    # wall clock without the per-launch timing events (two event records per launch are visible there), then a
+    # shorter pass with them for the kernel duration
+    s_steps, _, s_wall, _, _ = r.measure(steps, steps // 4, None, args.prewarm_ms, time_kernels=False)
+    _, _, _, k_ms, k_launches = r.measure(steps // 4, 0, None, 0.0)
+    per = k_ms / 1e3 / k_launches
+    out = {"value": round(C * N * s_steps / s_wall / 1e6, 1), "unit": "Msamples/s", "steps": s_steps,
+           "us_per_step": round(s_wall / s_steps * 1e6, 2), "avg_kernel_us": round(per * 1e6, 2),
+           "roofline_frac": round(alg_bytes * C * N / per / 1e9 / HBM_PEAK_GBS, 4),
+           "ring_slots": r.eng.ring_slots,
+           "note": "one launch per step through the zero-copy ring (adsp_apply_ring), N outputs kept per transform"}
+    if r.graph is not None:
+        g_steps = -(-steps // r.graph_steps) * r.graph_steps
+        g_steps, _, g_wall, _, _ = r.measure(g_steps, r.graph_steps, None, args.prewarm_ms / 3, time_kernels=False, graph=True)
+        out["graph"] = {"value": round(C * N * g_steps / g_wall / 1e6, 1), "us_per_step": round(g_wall / g_steps * 1e6, 2),
+                        "roofline_frac": round(alg_bytes * C * N * g_steps / g_wall / 1e9 / HBM_PEAK_GBS, 4),
+                        "steps_per_replay": r.graph_steps,
+                        "note": "the same single-step launches captured once and replayed as a hipGraph (wall clock over whole replays)"}
+    elif getattr(r, "graph_error", None):
+        out["graph"] = {"error": r.graph_error}
+    del r
+    torch.cuda.empty_cache()
+    return out
+
+
+def numpy_api_latency(n=4096, reps=1500):
+    """What a drop-in user of the reference API sees: dev.apply(numpy chunk) -> numpy chunk, one mono channel."""
+    import pyaudiodsptools_amd as adsp
+    adsp.config.initialize(44100, n)
+    dev = adsp.CreateLowCutFilter(800)
+    x = np.random.default_rng(0).uniform(-1, 1, n).astype(np.float32)
+    for _ in range(200):
+        dev.apply(x)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dev.apply(x)
+    return (time.perf_counter() - t0) / reps * 1e6
 
 
 def main():
@@ -232,7 +309,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     barrier = None
-    if world > 1:
+    if world > 1 or os.environ.get("ADSP_BENCH_FORCE_PG") == "1":  # FORCE_PG: run the RCCL broadcast at world size 1
         adist.init_process_group(backend)
         import torch.distributed as tdist
         barrier = tdist.barrier
@@ -246,36 +323,44 @@ def main():
         t = torch.tensor([wall, kern_ms], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         wall, kern_ms = float(t[0]), float(t[1])
+    sps, cps = main_run.samples_per_step, main_run.cps
+    eng_desc = {"fft_size": main_run.eng.geometry.fft_size, "real": main_run.eng.real_spectrum,
+                "kept": N if args.mode == "stream" else main_run.eng.block_outputs, "taps": len(fir.taps)}
 
-    extra_stream = None
-    if args.mode != "stream" and not args.no_stream_extra and world == 1:
-        del main_run.ins
+    extra_stream = latency = None
+    if world == 1 and args.mode != "stream" and not args.no_stream_extra:
+        del main_run.ins, main_run.outs
         torch.cuda.empty_cache()
-        s_run = Runner(args, "stream", fir, dev, local_rank, world, rank)
-        # wall clock without the per-launch timing events (two event records per 50 us launch are visible there), then a
-        # shorter pass with them for the kernel duration
-        s_steps, _, s_wall, _, _ = s_run.measure(2048, 512, None, args.prewarm_ms, time_kernels=False)
-        _, _, _, s_kern_ms, s_launches = s_run.measure(512, 0, None, 0.0)
-        s_per = s_kern_ms / 1e3 / s_launches
-        extra_stream = {"value": round(C * N * s_steps / s_wall / 1e6, 1), "unit": "Msamples/s", "steps": s_steps,
-                        "avg_kernel_us": round(s_per * 1e6, 2),
-                        "roofline_frac": round(alg_bytes * C * N / s_per / 1e9 / HBM_PEAK_GBS, 4),
-                        "note": "one launch per step through the zero-copy ring (adsp_apply_ring), N outputs kept per 2N transform"}
+        extra_stream = stream_figures(args, fir, dev, local_rank, world, rank, alg_bytes)
+    if world == 1 and not args.no_latency and args.io == "f32" and args.effect == "none":
+        # SURVEY 8d "also report": config 3 in its real-time call pattern and the numpy-API call
+        if args.mode != "stream" and hasattr(main_run, "ins"):
+            del main_run.ins, main_run.outs
+            torch.cuda.empty_cache()
+        a3 = parse(["--filter", "eq3", "--chunk", "512", "--fs", "44100", "--channels", "4096"] + (["--no-graph"] if args.no_graph else []))
+        a3.prewarm_ms = min(args.prewarm_ms, 100.0)
+        s3 = stream_figures(a3, make_fir(a3), dev, local_rank, world, rank, ALG_BYTES_PER_SAMPLE, steps=4096)
+        latency = {"config3_eq3_2048_stereo_pairs_x_512": {k: s3[k] for k in ("us_per_step", "avg_kernel_us", "value", "roofline_frac", "graph") if k in s3},
+                   "numpy_api_apply_us_per_call": round(numpy_api_latency(), 2),
+                   "note": "config 3 = CreateEQ3BandFFT(100,2,700,-4,8000,5) on 4096 mono channels (2048 stereo pairs) x 512 samples, one launch "
+                           "per step (zero-copy ring); numpy API = CreateLowCutFilter(800).apply(float32[4096]) -> float32[4096], 1 channel, host "
+                           "buffers (PCIe + launch bound, never `value`)"}
 
     if rank == 0:
-        eng = main_run.eng
-        value = C * N * world * steps / wall / 1e6
+        value = sps * world * steps / wall / 1e6
         per_launch_s = kern_ms / 1e3 / launches
-        samples_per_launch = C * N * steps / launches  # average: a --steps that is no multiple of the launch size ends short
+        samples_per_launch = sps * steps / launches
         achieved = alg_bytes * samples_per_launch / per_launch_s / 1e9
         mode_key = "stream" if args.mode == "stream" else "batch"
-        traffic = None
+        traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
-                rec = json.load(open(tf)).get(f"{args.filter}_{C}x{N}_{mode_key}" + ("" if args.io == "f32" else "_s16"))
-                if rec and rec.get("steps_per_launch", main_run.spl) == main_run.spl and steps % main_run.spl == 0:
-                    traffic = rec.get("hbm_bytes_per_launch")
+                key = f"{args.filter}_{C}x{N}_{mode_key}" + ("" if args.io == "f32" else "_s16")
+                rec = json.load(open(tf)).get(key)
+                if rec:  # measured per launch at rec["steps_per_launch"] chunks; scale by the chunk count (traffic is linear in it)
+                    traffic = int(rec["hbm_bytes_per_launch"] * (cps / rec.get("steps_per_launch", cps)))
+                    traffic_src = rec.get("source")
             except Exception:
                 traffic = None
         line = {
@@ -291,24 +376,29 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if args.io == "f32" else "f32 arithmetic on s16 samples",
             "data": ("synthetic uniform(-1,1) float32" if args.io == "f32" else "synthetic uniform int16 PCM (-6 dBFS)") + " resident in HBM " +
-                    ("(library input ring)" if args.mode == "stream" else "([steps, channels, chunk] batches)"),
+                    ("(library input ring)" if args.mode == "stream" else "([chunks, channels, chunk] batches)"),
             "config": {"workload": f"{FILTER_NAMES[args.filter]}{'' if args.effect == 'none' else ' -> ' + args.effect} @ {args.fs} Hz, {C} mono channels x {N}-sample chunks per GPU",
-                       "channels_per_gpu": C, "chunk_size": N, "mode": mode_key, "steps_per_launch": main_run.spl,
-                       "clock_ramp_prewarm_ms": args.prewarm_ms,
-                       "fft_size": eng.geometry.fft_size, "spectrum": "real (zero-phase kernel)" if eng.real_spectrum else "complex",
-                       "outputs_per_transform": (N if args.mode == "stream" else eng.block_outputs),
+                       "step": (f"one launch over a resident [{cps} chunks, {C} channels, {N} samples] batch" if mode_key == "batch"
+                                else f"one launch over a [{C} channels, {N} samples] batch (zero-copy ring)"),
+                       "channels_per_gpu": C, "chunk_size": N, "mode": mode_key, "chunks_per_step": cps, "samples_per_step": sps,
+                       "clock_ramp_prewarm_ms": args.prewarm_ms, "kernel_taps": eng_desc["taps"],
+                       "fft_size": eng_desc["fft_size"], "spectrum": "real (zero-phase kernel)" if eng_desc["real"] else "complex",
+                       "outputs_per_transform": eng_desc["kept"],
                        "parallelism": f"channel-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "adsp::fftconv_kernel", "avg_launch_us": round(per_launch_s * 1e6, 2),
-                         "launches": launches, "algorithmic_bytes_per_launch": int(alg_bytes * samples_per_launch)},
+                         "launches": launches, "algorithmic_bytes_per_launch": int(alg_bytes * samples_per_launch),
+                         "traffic_source": traffic_src},
         }
         if extra_stream:
             line["stream"] = extra_stream
+        if latency:
+            line["latency"] = latency
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if barrier is not None:
         tdist.barrier()
         tdist.destroy_process_group()
 

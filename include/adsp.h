@@ -41,7 +41,7 @@ extern "C" {
 #define ADSP_API
 #endif
 
-#define ADSP_ABI_VERSION 3
+#define ADSP_ABI_VERSION 4
 #define ADSP_MAX_HISTORY 8
 
 typedef enum adsp_status {
@@ -85,7 +85,7 @@ typedef struct adsp_config {
                             anything else runs the generic-geometry kernel */
     int history_chunks;  /* past chunks the window can reach (1..ADSP_MAX_HISTORY) */
     int lookback;        /* see above; 0 < lookback <= history_chunks*N; multiple of N/4 (specialised) or 4 (generic) */
-    int out_offset;      /* see above; multiple of 2*threads_per_transform (specialised) or 4* (generic) */
+    int out_offset;      /* see above; multiple of N/4 (specialised) or 4*threads_per_transform (generic) */
     int ring_slots;      /* input ring length (>= history_chunks+1); 0 = 2*history_chunks, which lets the ring
                             update of multi-step launches run on a side stream beside the kernel */
     int sample_format;   /* ADSP_FORMAT_F32 or ADSP_FORMAT_S16: type of every `in`/`out`/ring/state buffer below */
@@ -126,9 +126,15 @@ ADSP_API int adsp_set_spectrum_device(adsp_engine* engine, const float* d_spectr
  * 0): the kernel then runs its cheaper spectrum stage.  0 otherwise. */
 ADSP_API int adsp_spectrum_is_real(const adsp_engine* engine, int* is_real);
 
+/* Optional hint that saves input traffic: how many taps of the (circularly placed) kernel sit at NEGATIVE circular
+ * indices - 0 for a causal kernel, (L-1)/2 for a zero-phase one centred on index 0.  Window positions at or beyond
+ * out_offset + block_outputs + reach then feed discarded outputs only and are not fetched: a single-step launch of the
+ * reference's cut filters reads 1.5 N instead of 2 N samples per chunk.  Negative = unknown (default): fetch everything. */
+ADSP_API int adsp_set_kernel_reach(adsp_engine* engine, int taps_at_negative_indices);
+
 /* Samples kept per transform in multi-step launches (apply_device with n_steps > 1).  Default is
- * chunk_size; any multiple of 2*threads_per_transform up to fft_size - out_offset is valid and
- * larger is cheaper (1.5 N for the cut filters at F = 2N). */
+ * chunk_size; any multiple of N/4 (specialised kernels; 4*threads_per_transform for the generic one) up to
+ * fft_size - out_offset is valid and larger is cheaper (1.5 N for the cut filters at F = 2N). */
 ADSP_API int adsp_set_block_outputs(adsp_engine* engine, int block_outputs);
 
 /* Stateless effects, fused on the filter kernel's output registers (no extra HBM traffic) or run as a

@@ -1,0 +1,117 @@
+"""CPU-baseline timing of the oracle (bench.py's `cpu_baseline` leg ONLY - test infrastructure, never the product path).
+
+BASELINE.md section 4 / SURVEY.md 8d(ii): the reference's algorithm restated in numpy, timed the way the reference's own
+ModuleTests.py:168-178 times it (time.perf_counter around a loop of .apply(chunk) calls), in two arithmetic variants
+  literal3n : the reference's literal form, 3N complex fft/ifft per chunk (oracle.fftfilter_oracle.OracleLowCut/...)
+  rfft2n    : overlap-save with a 2N real FFT, the arithmetic the HIP kernel performs (OracleRfft2N)
+and two process layouts: one process, and one process per physical core over disjoint channels (numpy's pocketfft is
+single-threaded, so cores are filled with processes - what a user of the reference with many channels would do).
+"""
+import multiprocessing as mp
+import os
+import time
+
+import numpy as np
+
+
+def physical_cores():
+    """Distinct (socket, core) pairs among the CPUs this process may run on; falls back to half the logical count."""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    pairs, cur = set(), {}
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if ":" in line:
+                    k, v = (t.strip() for t in line.split(":", 1))
+                    cur[k] = v
+                elif not line.strip():
+                    if cur.get("processor", "").isdigit() and int(cur["processor"]) in allowed and "core id" in cur:
+                        pairs.add((cur.get("physical id", "0"), cur["core id"]))
+                    cur = {}
+        if cur.get("processor", "").isdigit() and int(cur["processor"]) in allowed and "core id" in cur:
+            pairs.add((cur.get("physical id", "0"), cur["core id"]))
+    except OSError:
+        pass
+    return len(pairs) if pairs else max(1, len(allowed) // 2)
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _make_device(filter_name, variant, n, fs, channels):
+    from oracle import fftfilter_oracle as orc
+    if variant == "literal3n":
+        if filter_name == "lowcut":
+            return orc.OracleLowCut(800, fs, n)
+        if filter_name == "highcut":
+            return orc.OracleHighCut(8000, fs, n)
+        if filter_name == "eq3":
+            return orc.OracleEQ3BandFFT(100, 2, 700, -4, 8000, 5, fs, n)
+        a, b, c = (orc.OracleLowCut(800, fs, n), orc.OracleEQ3BandFFT(100, 2, 700, -4, 8000, 5, fs, n),
+                   orc.OracleHighCut(8000, fs, n))
+
+        class _Chain:  # three devices in series, one chunk of latency each - what config 5 costs the reference
+            def apply(self, x):
+                return c.apply(b.apply(a.apply(x)))
+        return _Chain()
+    taps = {"lowcut": lambda: orc.lowcut_taps(800, fs, n), "highcut": lambda: orc.highcut_taps(8000, fs, n),
+            "eq3": lambda: orc.eq3_composite_taps(100, 2, 700, -4, 8000, 5, fs, n)}.get(filter_name)
+    if taps is None:
+        return None  # the fused chain does not fit a 2N transform
+    return orc.OracleRfft2N(taps(), n, channels=channels)
+
+
+def run_worker(job):
+    """(filter_name, variant, n, fs, channels_per_call, seconds, seed) -> (samples filtered, elapsed seconds)."""
+    filter_name, variant, n, fs, channels, seconds, seed = job
+    dev = _make_device(filter_name, variant, n, fs, channels)
+    if dev is None:
+        return 0, 0.0
+    rng = np.random.default_rng(seed)
+    shape = (n,) if variant == "literal3n" else (channels, n)
+    chunks = [rng.uniform(-1, 1, shape).astype(np.float32) for _ in range(32)]
+    for ch in chunks[:8]:
+        dev.apply(ch)
+    done = 0
+    t0 = time.perf_counter()
+    while True:
+        for ch in chunks:
+            dev.apply(ch)
+        done += len(chunks)
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            break
+    return done * int(np.prod(shape)), el
+
+
+def measure(filter_name, n, fs, seconds_each=5.0, rfft_channels=16):
+    """All four figures in Msamples/s (None where a variant does not apply)."""
+    cores = physical_cores()
+    out = {"physical_cores": cores, "logical_cpus": os.cpu_count(), "cpu_model": cpu_model(), "numpy": np.__version__}
+    ctx = mp.get_context("spawn")  # the parent holds a HIP context: never fork it
+    for variant, chans in (("literal3n", 1), ("rfft2n", rfft_channels)):
+        samples, el = run_worker((filter_name, variant, n, fs, chans, seconds_each, 1234))
+        out[f"{variant}_1proc"] = round(samples / el / 1e6, 3) if el else None
+        if not el:
+            out[f"{variant}_allcores"] = None
+            continue
+        jobs = [(filter_name, variant, n, fs, chans, seconds_each, 1234 + i) for i in range(cores)]
+        t0 = time.perf_counter()
+        with ctx.Pool(cores) as pool:
+            res = pool.map(run_worker, jobs)
+        wall = time.perf_counter() - t0
+        # every process times its own steady state; the aggregate is the sum of the per-process rates
+        out[f"{variant}_allcores"] = round(sum(s / e for s, e in res if e) / 1e6, 3)
+        out[f"{variant}_allcores_wall_s"] = round(wall, 2)
+    return out

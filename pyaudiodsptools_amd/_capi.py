@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADSP_LIB") or os.path.join(_HERE, "libadsp.so")  # ADSP_LIB: tuning builds only
 
-ADSP_ABI_VERSION = 3
+ADSP_ABI_VERSION = 4
 ADSP_MAX_HISTORY = 8
 ADSP_FORMAT_F32, ADSP_FORMAT_S16 = 0, 1
 EFFECT_NONE, EFFECT_VOLUME, EFFECT_SOFT_CLIPPER, EFFECT_HARD_DISTORTION, EFFECT_SATURATOR, EFFECT_TREMOLO = 0, 1, 2, 3, 4, 5
@@ -59,6 +59,7 @@ SIGNATURES = {
     "adsp_destroy": (ctypes.c_int, [_engine_p]),
     "adsp_set_spectrum": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_int]),
     "adsp_set_spectrum_device": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "adsp_set_kernel_reach": (ctypes.c_int, [_engine_p, ctypes.c_int]),
     "adsp_set_block_outputs": (ctypes.c_int, [_engine_p, ctypes.c_int]),
     "adsp_spectrum_is_real": (ctypes.c_int, [_engine_p, _c_int_p]),
     "adsp_set_epilogue": (ctypes.c_int, [_engine_p, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float]),

@@ -233,6 +233,7 @@ struct adsp_engine {
     char* zeros;   // 4*chunk_size zero bytes
     bool have_spectrum;
     bool real_spec;  // every Im H == 0: the kernel takes the 3-real-constants-per-pair path
+    int kernel_reach;  // kernel taps at negative circular indices (adsp_set_kernel_reach); < 0 = unknown: load the whole window
     char* stage_in;
     char* stage_out;
     size_t stage_elems;  // capacity in samples
@@ -360,6 +361,14 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
     if (total + 8LL * c.fft_size >= 0x7fffffffLL)  // the kernel indexes a channel's time axis with 32-bit ints
         return fail(ADSP_ERR_ARG, "n_steps %d x chunk %d is too long for one call; split it", n_steps, c.chunk_size);
     a.nblk = (int)((total + a.V - 1) / a.V);
+    // window positions >= out_offset + V + reach feed discarded outputs only: whole register pairs (4T samples) beyond
+    // them are not fetched
+    a.win_pairs = pl.P / 2;
+    if (e->kernel_reach >= 0) {
+        const int need = c.out_offset + a.V + e->kernel_reach, seg = 4 * pl.T;
+        const int pairs = (need + seg - 1) / seg;
+        if (pairs < a.win_pairs) a.win_pairs = pairs;
+    }
     a.lookback = c.lookback;
     a.j0 = c.out_offset;
     a.ncg = (c.n_channels + pl.CPB - 1) / pl.CPB;
@@ -434,10 +443,15 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     if (cfg->history_chunks < 1 || cfg->history_chunks > ADSP_MAX_HISTORY)
         return fail(ADSP_ERR_ARG, "history_chunks %d out of range 1..%d", cfg->history_chunks, ADSP_MAX_HISTORY);
     if (!generic) {
-        if (cfg->lookback <= 0 || cfg->lookback > cfg->history_chunks * N || cfg->lookback % T2)
-            return fail(ADSP_ERR_ARG, "lookback %d must be in (0, history_chunks*N] and a multiple of %d", cfg->lookback, T2);
-        if (cfg->out_offset < 0 || cfg->out_offset % T2 || cfg->out_offset + N > F)
-            return fail(ADSP_ERR_ARG, "out_offset %d must be a multiple of %d with out_offset + N <= F", cfg->out_offset, T2);
+        // the specialised kernels resolve the window / kept-slice phase in QUARTER chunks (a 4-way switch on
+        // (t & (N-1)) >> (log2 N - 2)) and store whole register pairs: everything on the time axis is a multiple of N/4
+        // (whole registers for every plan, whole register pairs for the plans with 16-byte I/O)
+        const int Q4 = N / 4;
+        if (Q4 % T2) return fail(ADSP_ERR_STATE, "internal: N/4 = %d is not a multiple of %d", Q4, T2);
+        if (cfg->lookback <= 0 || cfg->lookback > cfg->history_chunks * N || cfg->lookback % Q4)
+            return fail(ADSP_ERR_ARG, "lookback %d must be in (0, history_chunks*N] and a multiple of N/4 = %d", cfg->lookback, Q4);
+        if (cfg->out_offset < 0 || cfg->out_offset % Q4 || cfg->out_offset + N > F)
+            return fail(ADSP_ERR_ARG, "out_offset %d must be a multiple of N/4 = %d with out_offset + N <= F", cfg->out_offset, Q4);
     } else {
         // generic geometry: 16-byte accesses need everything on the time axis to be a multiple of 4 samples; kept
         // ranges are whole register segments (2T samples)
@@ -491,6 +505,7 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     e->zeros = nullptr;
     e->have_spectrum = false;
     e->real_spec = false;
+    e->kernel_reach = -1;
     e->stage_in = e->stage_out = nullptr;
     e->stage_elems = 0;
     e->pin_in[0] = e->pin_in[1] = e->pin_out = nullptr;
@@ -588,9 +603,17 @@ int adsp_spectrum_is_real(const adsp_engine* e, int* is_real) {
     return ADSP_OK;
 }
 
+int adsp_set_kernel_reach(adsp_engine* e, int taps_at_negative_indices) {
+    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    if (taps_at_negative_indices >= e->cfg.fft_size) return fail(ADSP_ERR_ARG, "kernel reach %d >= fft_size", taps_at_negative_indices);
+    e->kernel_reach = taps_at_negative_indices < 0 ? -1 : taps_at_negative_indices;
+    return ADSP_OK;
+}
+
 int adsp_set_block_outputs(adsp_engine* e, int v) {
     if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
-    const int T2 = (e->generic ? 4 : 2) * e->plan->T;  // the generic kernel keeps whole register pairs
+    // generic kernel: whole register pairs; specialised kernels: quarter chunks (their store phase is a 4-way switch)
+    const int T2 = e->generic ? 4 * e->plan->T : e->cfg.chunk_size / 4;
     if (v <= 0 || v % T2 || e->cfg.out_offset + v > e->cfg.fft_size)
         return fail(ADSP_ERR_ARG, "block_outputs %d must be a positive multiple of %d with out_offset + block_outputs <= fft_size", v, T2);
     // the window must not need input newer than what a block's last output may see:
@@ -775,6 +798,10 @@ int adsp_reset(adsp_engine* e) {
     e->copy_pending = false;
     HIP_TRY(hipMemset(e->ring, 0, (size_t)e->cfg.ring_slots * e->plane_bytes()));
     e->ring_pos = e->cfg.ring_slots - 1;
+    // a fused tremolo starts over as well (the reference pair would be filter.reset + a fresh CreateTremolo)
+    e->lfo_copy_len = e->lfo_len;
+    e->epi_phase = 0;
+    e->epi_replay = 0;
     return ADSP_OK;
 }
 

@@ -85,6 +85,9 @@ struct KernelArgs {
     float epi_p0, epi_p1, epi_p2;
     int epi_phase;         // tremolo: LFO table index of this launch's output sample 0
     int epi_replay;        // tremolo: the table index restarts at epi_phase with EVERY chunk (the reference's stuck buffer)
+    int win_pairs;         // register PAIRS of the window that are loaded (P/2 = all); the rest is taken as zero: window
+                           // positions >= out_offset + V + (kernel taps at negative circular indices) only feed discarded
+                           // outputs - a single-step launch of a zero-phase cut filter needs 1.5 N of its 2 N window
     int accumulate;        // 1: add the kept samples to what `out` holds (partitioned FIRs, mixing); 2: and clip the sum
                            // to [-1, 1] (MixSignals).  Plain kernels: generic geometry + mode 1 only; EPI kernels: all.
 };
@@ -643,7 +646,7 @@ __device__ __forceinline__ float lane_xor1(float v) {
 // `cb`/`ob` pointers passed in already carry the per-lane adjustment (+2T-2 floats on odd lanes).
 template <class PL, int FN, int RQ>
 __device__ __forceinline__ void load_window(const float* const (&cb)[FN + 1], float (&xr)[PL::P], float (&xi)[PL::P],
-                                            bool odd, bool nt) {
+                                            bool odd, bool nt, int win_pairs) {
     constexpr int P = PL::P, T = PL::T, MPC = P / FN, Q = MPC / 4;
     static_assert(MPC % 4 == 0, "need at least 4 registers per chunk");
     if constexpr (ADSP_WIDE_IO && Q % 2 == 0) {
@@ -661,7 +664,7 @@ __device__ __forceinline__ void load_window(const float* const (&cb)[FN + 1], fl
                 const v4f nv = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(cb[gi / MPC] + (gi % MPC) * 2 * T));
                 v[u] = make_float4(nv.x, nv.y, nv.z, nv.w);
             }
-        } else {
+        } else if (win_pairs >= P / 2) {
 #pragma unroll
             for (int u = 0; u < P / 2; ++u) {
                 const int gi = RQ * Q + 2 * u;
@@ -672,6 +675,14 @@ __device__ __forceinline__ void load_window(const float* const (&cb)[FN + 1], fl
 #else
                 v[u] = *reinterpret_cast<const float4*>(cb[i] + off);
 #endif
+            }
+        } else {
+            // the tail of the window only feeds discarded outputs (KernelArgs::win_pairs): not fetched
+#pragma unroll
+            for (int u = 0; u < P / 2; ++u) {
+                const int gi = RQ * Q + 2 * u;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (u < win_pairs) v[u] = *reinterpret_cast<const float4*>(cb[gi / MPC] + (gi % MPC) * 2 * T);  // wave-uniform
             }
         }
 #if ADSP_LOAD_FENCE
@@ -1065,10 +1076,10 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(con
         }
     } else {
         switch ((t0 & (N - 1)) >> (LOGN - 2)) {
-            case 0: load_window<PL, FN, 0>(cb, xr, xi, odd, a.n_steps > 1); break;
-            case 1: load_window<PL, FN, 1>(cb, xr, xi, odd, a.n_steps > 1); break;
-            case 2: load_window<PL, FN, 2>(cb, xr, xi, odd, a.n_steps > 1); break;
-            default: load_window<PL, FN, 3>(cb, xr, xi, odd, a.n_steps > 1); break;
+            case 0: load_window<PL, FN, 0>(cb, xr, xi, odd, a.n_steps > 1, a.win_pairs); break;
+            case 1: load_window<PL, FN, 1>(cb, xr, xi, odd, a.n_steps > 1, a.win_pairs); break;
+            case 2: load_window<PL, FN, 2>(cb, xr, xi, odd, a.n_steps > 1, a.win_pairs); break;
+            default: load_window<PL, FN, 3>(cb, xr, xi, odd, a.n_steps > 1, a.win_pairs); break;
         }
     }
 
@@ -1115,12 +1126,13 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(con
 // float reciprocal division per lane.  Same transform core, ~15 % more VALU for the address arithmetic.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void locate_chunk(int tau_biased, int N, float inv_n, int& q, int& r) {
-    q = static_cast<int>(static_cast<float>(tau_biased) * inv_n);  // may be off by one either way
-    r = tau_biased - q * N;
-    if (r < 0) {
+    q = static_cast<int>(static_cast<float>(tau_biased) * inv_n);  // estimate: off by one at most while tau < 2^24,
+    r = tau_biased - q * N;                                        // by a few chunks beyond (float(tau) is inexact there)
+    while (r < 0) {
         --q;
         r += N;
-    } else if (r >= N) {
+    }
+    while (r >= N) {
         ++q;
         r -= N;
     }

@@ -18,7 +18,7 @@ Differences that are deliberate (SURVEY.md section 7 "Hard parts"):
 import numpy as np
 
 from . import config
-from .design import (FirStream, eq3_composite, eq3_kernels, filter_length, highcut_kernel, lowcut_kernel,
+from .design import (TRIM_EPS, FirStream, eq3_composite, eq3_kernels, filter_length, highcut_kernel, lowcut_kernel,
                      reference_spectrum_3n)
 from .effects import Effect
 from .engine import FirEngine, make_engine
@@ -146,13 +146,16 @@ CreateLowCutFilterGPU = CreateLowCutFilter
 CreateEQ3BandFFTGPU = CreateEQ3BandFFT
 
 
-def fuse(*devices, channels=None, device=0, ring_slots=0):
+def fuse(*devices, channels=None, device=0, ring_slots=0, trim=None, optimize_for="stream"):
     """Series connection of FFT devices as ONE engine (config 5: LowCut -> EQ3 -> HighCut).
 
     The result computes, in a single kernel per step, what feeding each device's output into the
     next one's apply() computes in the reference: one FIR of summed length, latency = number of
     devices chunks.  A stateless effect (effects.CreateSoftClipper, ...) may follow the last device; it is applied to
-    the kernel's output registers (no extra pass)."""
+    the kernel's output registers (no extra pass).
+
+    `trim`: the composite kernel's negligible end taps are left out (FirStream.trimmed; default design.TRIM_EPS = 1e-8 of
+    sum|taps|, i.e. a worst-case output change of ~6e-8 of full scale for the config-5 chain); 0 keeps every tap."""
     devices = list(devices)
     effect = devices.pop() if isinstance(devices[-1], Effect) else None
     if not devices or any(isinstance(dev, Effect) for dev in devices):
@@ -160,8 +163,10 @@ def fuse(*devices, channels=None, device=0, ring_slots=0):
     fir = devices[0].fir
     for dev in devices[1:]:
         fir = fir.then(dev.fir)
+    if len(devices) > 1 and trim != 0:
+        fir = fir.trimmed(TRIM_EPS if trim is None else trim)
     ch = devices[0].channels if channels is None else channels
-    engine = FirEngine(fir, channels=ch, device=device, ring_slots=ring_slots)
+    engine = FirEngine(fir, channels=ch, device=device, ring_slots=ring_slots, optimize_for=optimize_for)
     if effect is not None:
         engine.set_epilogue(effect)
     return engine

@@ -50,7 +50,7 @@ def broadcast_spectrum(spectrum_f32, src=0, device=None):
     t = torch.from_numpy(np.ascontiguousarray(spectrum_f32, dtype=np.float32).copy())
     if device is not None:
         t = t.to(device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():  # also at world size 1: the collective path is the same code on one GPU and on eight
         dist.broadcast(t, src=src)
     return t, t.detach().cpu().numpy()
 
@@ -98,11 +98,19 @@ class ShardedFirBank:
         if engine_factory is None:
             from .engine import FirEngine
             engine_factory = FirEngine
+        if self.hi == self.lo:  # more ranks than channels: this rank idles (it still took part in the broadcasts)
+            self.engine = None
+            return
         self.engine = engine_factory(fir, channels=self.hi - self.lo, device=device, ring_slots=ring_slots,
                                      **({'fft_mult': fft_mult} if fft_mult else {}),
                                      **({'sample_format': sample_format} if sample_format != "f32" else {}),
                                      **({'optimize_for': optimize_for} if optimize_for != "stream" else {}))
-        # `self.spectrum` is the host copy taken after the collective completed on torch's stream; uploading from it
-        # avoids reading the device tensor from the library's own stream (adsp_set_spectrum_device exists for callers
-        # that manage that ordering themselves).
-        self.engine.upload_spectrum(self.spectrum)
+        if bdev is not None and hasattr(self.engine, "upload_spectrum_device"):
+            # RCCL path: the spectrum the collective left in this GPU's memory goes straight into the engine
+            # (adsp_set_spectrum_device); the collective ran on torch's current stream, which is drained first
+            import torch
+            torch.cuda.current_stream(bdev).synchronize()
+            self.engine.upload_spectrum_device(self.spectrum_tensor, n_floats // 2)
+        else:
+            # gloo / no process group: `self.spectrum` is the host copy taken after the collective completed
+            self.engine.upload_spectrum(self.spectrum)

@@ -76,6 +76,8 @@ class FirEngine:
         self.fir = fir
         self.spectrum = engine_spectrum(fir, geo, self.gain)
         self.upload_spectrum(self.spectrum)
+        # taps at negative circular indices: lets the kernel skip the part of the window that feeds discarded outputs
+        _capi.check(self._lib.adsp_set_kernel_reach(self._h, max(0, -geo.shift)))
 
     def upload_spectrum(self, spectrum_f32):
         spec = np.ascontiguousarray(spectrum_f32, dtype=np.float32)

@@ -134,13 +134,24 @@ def test_chain_fused_E(adsp, golden):
     adsp.config.initialize(fs, n)
     eng = adsp.fuse(adsp.CreateLowCutFilter(800), adsp.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5),
                     adsp.CreateHighCutFilter(8000))
-    assert eng.geometry.fft_size == 4 * n and eng.geometry.history_chunks == 5
+    # the composite's 6976 negligible end taps are left out by default (FirStream.trimmed): 9401 of 16377 taps, so a
+    # 4N transform keeps 2.75 N samples and the window reaches 4 chunks back
+    assert eng.geometry.fft_size == 4 * n and eng.geometry.history_chunks == 4 and len(eng.fir.taps) == 9401
+    assert eng.geometry.max_block_outputs == 11 * n // 4
     x = seeded_stream(4321, 12 * n).reshape(12, 1, n)
     y = np.concatenate([eng.apply_host(x[k])[0] for k in range(12)])
     assert_parity(y, golden["kat_chain"]["E"], what="chain streaming")
     eng.reset()
     y2 = eng.apply_host(x).reshape(-1)  # all 12 steps in one launch (multi-step blocks)
     assert_parity(y2, golden["kat_chain"]["E"], what="chain offline")
+    # every tap kept (trim=0): the round-1 geometry, 2 N kept per 4N transform
+    full = adsp.fuse(adsp.CreateLowCutFilter(800), adsp.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5),
+                     adsp.CreateHighCutFilter(8000), trim=0)
+    assert full.geometry.history_chunks == 5 and len(full.fir.taps) == 16377 and full.geometry.max_block_outputs == 2 * n
+    y3 = full.apply_host(x).reshape(-1)
+    assert_parity(y3, golden["kat_chain"]["E"], what="chain offline, untrimmed")
+    # what trimming costs: far below the float32 pipeline's own rounding
+    assert np.abs(y3 - y2).max() <= 2e-6 * np.abs(y3).max()
 
 
 @pytest.mark.parametrize("n,channels", [(64, 37), (128, 9), (256, 5), (512, 7), (1024, 3), (2048, 2), (4096, 5), (8192, 2)])
@@ -396,6 +407,146 @@ def test_config3_full_size_eq_stereo_pairs(adsp):
         assert_parity(yh[:, c].reshape(-1), o.direct_stream_convolution(taps, xh[:, c].reshape(-1), n), what=f"config3 ch {c}")
 
 
+def test_config4_full_size_properties(adsp):
+    """config 4's per-GPU shape: 8192 channels x 4096 samples, HighCut(8000) - impulse response == taps, silence,
+    linearity, sampled channels against the float64 direct convolution; streaming and one multi-step launch."""
+    import torch
+    o = orc()
+    n, channels, steps, fs = 4096, 8192, 3, 44100
+    adsp.config.initialize(fs, n)
+    dev = adsp.CreateHighCutFilter(8000, channels=channels)
+    eng = dev.engine
+    taps = o.highcut_taps(8000, fs, n)
+    g = torch.Generator(device="cuda").manual_seed(15)
+    x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=g)
+    x[:, 0] = 0
+    x[0, 0, n - 1] = 1.0  # channel 0: unit impulse on the last sample of the first chunk
+    x[:, 1] = 0           # channel 1: silence
+    y = torch.empty_like(x)
+    s = torch.cuda.current_stream().cuda_stream
+    for k in range(steps):
+        eng.apply_device(x[k], y[k], 1, s)
+    torch.cuda.synchronize()
+    yh = y.cpu().numpy()
+    assert np.isfinite(yh).all() and not yh[:, 1].any()
+    d = n // 4 - 1
+    imp = yh[:, 0].reshape(-1)
+    start = n - d + (n - 1)
+    assert np.abs(imp[start:start + len(taps)] - taps).max() <= 1e-5 * np.abs(taps).max()
+    assert np.abs(np.delete(imp, np.arange(start, start + len(taps)))).max() <= 2e-6
+    xh = x.cpu().numpy()
+    for c in (2, 4097, channels - 1):
+        assert_parity(yh[:, c].reshape(-1), o.direct_stream_convolution(taps, xh[:, c].reshape(-1), n), what=f"config4 ch {c}")
+    eng.reset()
+    y_all = torch.empty_like(x)
+    eng.apply_device(x, y_all, steps, s)  # one launch, 1.5 N kept per transform
+    torch.cuda.synchronize()
+    assert float((y_all - y).abs().max()) <= 2e-6
+    eng.reset()
+    z = torch.empty_like(x).uniform_(-1, 1, generator=g)
+    y_mix, y_z = torch.empty_like(x), torch.empty_like(x)
+    eng.apply_device(0.5 * x + 0.25 * z, y_mix, steps, s)
+    eng.reset()
+    eng.apply_device(z, y_z, steps, s)
+    torch.cuda.synchronize()
+    lin = 0.5 * y + 0.25 * y_z
+    assert float((y_mix - lin).abs().max()) <= 1e-5 * float(lin.abs().max())
+
+
+def test_config5_full_size_properties(adsp):
+    """config 5's per-GPU shape: 4096 channels x 8192 samples @ 96 kHz, LowCut -> EQ3 -> HighCut as ONE engine - impulse
+    response == the full 16377-tap composite, silence, linearity, sampled channels against the float64 direct
+    convolution of the three devices in series; one multi-step launch (2.75 N kept per 4N transform) and streaming."""
+    import torch
+    from pyaudiodsptools_amd import design
+    o = orc()
+    n, channels, steps, fs = 8192, 4096, 11, 96000
+    adsp.config.initialize(fs, n)
+    eng = adsp.fuse(adsp.CreateLowCutFilter(800), adsp.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5),
+                    adsp.CreateHighCutFilter(8000), channels=channels, optimize_for="batch")
+    chain = (design.FirStream(o.lowcut_taps(800, fs, n), n).then(design.FirStream(o.eq3_composite_taps(100, 2, 700, -4, 8000, 5, fs, n), n))
+             .then(design.FirStream(o.highcut_taps(8000, fs, n), n)))
+    taps = chain.taps  # every tap: the engine runs the trimmed kernel, the truth does not
+    assert len(taps) == 16377 and chain.latency_chunks == 3
+    g = torch.Generator(device="cuda").manual_seed(16)
+    x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=g)
+    x[:, 0] = 0
+    x[1, 0, 5] = 1.0  # channel 0: unit impulse
+    x[:, 1] = 0       # channel 1: silence
+    y = torch.empty_like(x)
+    s = torch.cuda.current_stream().cuda_stream
+    eng.apply_device(x, y, steps, s)
+    torch.cuda.synchronize()
+    yh = y.cpu().numpy()
+    assert np.isfinite(yh).all() and not yh[:, 1].any()
+    imp = yh[:, 0].reshape(-1)
+    start = chain.delay + n + 5  # out[tau] = sum c[t] s[tau - delay - t]
+    assert np.abs(imp[start:start + len(taps)] - taps).max() <= 1e-5 * np.abs(taps).max()
+    assert np.abs(np.delete(imp, np.arange(start, start + len(taps)))).max() <= 2e-6
+    xh = x.cpu().numpy()
+    for c in (2, 2049, channels - 1):
+        truth = o.direct_stream_convolution(taps, xh[:, c].reshape(-1), n, chain.latency_chunks, chain.lookahead)
+        assert_parity(yh[:, c].reshape(-1), truth, what=f"config5 ch {c}")
+    # streaming (one launch per chunk) == the multi-step launch
+    eng.reset()
+    y_s = torch.empty_like(x)
+    for k in range(steps):
+        eng.apply_device(x[k], y_s[k], 1, s)
+    torch.cuda.synchronize()
+    assert float((y_s - y).abs().max()) <= 4e-6
+    eng.reset()
+    z = torch.empty_like(x).uniform_(-1, 1, generator=g)
+    y_mix, y_z = torch.empty_like(x), torch.empty_like(x)
+    eng.apply_device(0.5 * x + 0.25 * z, y_mix, steps, s)
+    eng.reset()
+    eng.apply_device(z, y_z, steps, s)
+    torch.cuda.synchronize()
+    lin = 0.5 * y + 0.25 * y_z
+    assert float((y_mix - lin).abs().max()) <= 1e-5 * float(lin.abs().max())
+
+
+def test_sharded_bank_rccl_world1_real_engine(adsp):
+    """The N-GPU layer with the REAL HIP engine on the one GPU a test box has: init_process_group("nccl") (= RCCL),
+    the spectrum broadcast as a device tensor, uploaded with adsp_set_spectrum_device from the tensor the collective
+    left on the GPU.  World size 1 is all a one-GPU box can prove; the same code runs per rank on eight."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from pyaudiodsptools_amd import design
+    from pyaudiodsptools_amd.dist import ShardedFirBank, init_process_group
+    o = orc()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    init_process_group("nccl")
+    try:
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        n, fs, channels, steps = 4096, 44100, 48, 4
+        taps = o.lowcut_taps(800, fs, n)
+        bank = ShardedFirBank(design.FirStream(design.lowcut_kernel(800, fs, n), n), channels, device=0, optimize_for="batch")
+        assert (bank.lo, bank.hi) == (0, channels) and bank.spectrum_tensor.is_cuda
+        assert bank.engine.real_spectrum  # the zero-phase spectrum survived broadcast + device upload bit for bit
+        x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=torch.Generator(device="cuda").manual_seed(17))
+        y = torch.empty_like(x)
+        bank.engine.apply_device(x, y, steps, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        xh, yh = x.cpu().numpy(), y.cpu().numpy()
+        for c in (0, 17, channels - 1):
+            assert_parity(yh[:, c].reshape(-1), o.direct_stream_convolution(taps, xh[:, c].reshape(-1), n), what=f"rccl world-1 ch {c}")
+        # a second filter through the same path: complex spectrum (EQ), different geometry
+        eq = design.FirStream(design.eq3_composite(100, 2, 700, -4, 8000, 5, fs, 512), 512)
+        bank2 = ShardedFirBank(eq, 5, device=0)
+        assert not bank2.engine.real_spectrum
+        xe = np.random.default_rng(18).uniform(-1, 1, (6, 5, 512)).astype(np.float32)
+        ye = np.stack([bank2.engine.apply_host(xe[k]) for k in range(6)])
+        et = o.eq3_composite_taps(100, 2, 700, -4, 8000, 5, fs, 512)
+        assert_parity(ye[:, 3].reshape(-1), o.direct_stream_convolution(et, xe[:, 3].reshape(-1), 512), what="rccl world-1 eq")
+    finally:
+        dist.destroy_process_group()
+
+
 def test_raw_c_abi_error_paths(adsp):
     """Status codes + adsp_last_error() for misuse, straight through ctypes (no Python wrapper logic)."""
     import ctypes
@@ -410,8 +561,11 @@ def test_raw_c_abi_error_paths(adsp):
         h = ctypes.c_void_p()
         return lib.adsp_create(ctypes.byref(cfg), ctypes.byref(h)), h
 
+    # lookback 704 / out_offset 192 are multiples of 2*threads_per_transform (64) but not of N/4 (128): the specialised
+    # kernels resolve window and kept-slice phases in quarter chunks, so the ABI refuses them
     for bad in (dict(chunk_size=502), dict(fft_size=500), dict(fft_size=65536), dict(n_channels=0), dict(history_chunks=0), dict(lookback=641),
                 dict(lookback=4096), dict(out_offset=1000), dict(out_offset=768, lookback=640), dict(ring_slots=2),
+                dict(lookback=704), dict(out_offset=192),
                 dict(device_id=99), dict(sample_format=7)):
         rc, h = create(**bad)
         assert rc == _capi.ADSP_ERR_ARG and not h.value, bad
@@ -427,6 +581,9 @@ def test_raw_c_abi_error_paths(adsp):
     assert lib.adsp_apply_host(h, buf, buf, 0) == _capi.ADSP_ERR_ARG
     assert lib.adsp_apply_host(h, None, buf, 1) == _capi.ADSP_ERR_ARG
     assert lib.adsp_set_block_outputs(h, 4096) == _capi.ADSP_ERR_ARG
+    assert lib.adsp_set_block_outputs(h, 192) == _capi.ADSP_ERR_ARG    # not a multiple of N/4
+    assert lib.adsp_set_block_outputs(h, 640) == 0 and lib.adsp_set_block_outputs(h, 512) == 0
+    assert lib.adsp_set_kernel_reach(h, 1024) == _capi.ADSP_ERR_ARG and lib.adsp_set_kernel_reach(h, -1) == 0
     assert lib.adsp_apply_host(h, buf, buf, 1) == 0  # zero spectrum -> zero output, engine still healthy
     assert not any(buf)
     ms, n = ctypes.c_double(), ctypes.c_int()
