@@ -269,6 +269,33 @@ ADSP_API int adsp_scan_reset(adsp_scan* scan);
 ADSP_API int adsp_scan_apply_device(adsp_scan* scan, const float* d_in, float* d_out, int n_steps, void* stream);
 ADSP_API int adsp_scan_apply_host(adsp_scan* scan, const float* in, float* out, int n_steps);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Exact mode: the streaming FIR as a float64 DIRECT sum,  out[tau] = sum_t taps[t] * s[tau - delay - t]  per channel
+ * (zero history), for the reference's WAV front end where the export truncates: with ADSP_FORMAT_S16 the
+ * conversions are the reference's to the letter - float32(pcm)/32768 in (Utility.py:236-237), then
+ * int16(trunc(float32(y) * 32767)) out (EffectFFTFilter.py:75, Utility.py:306) - and the result is the int16 stream the
+ * reference writes, bit for bit wherever its own complex128 pipeline is within 1e-9 of the exact value.  O(taps) per
+ * sample: meant for files, not for the batched hot path.  With ADSP_FORMAT_F32 it returns float32(y): the on-device
+ * ground truth the parity tests compare every channel of the FFT engines with.
+ * For one reference device: taps = the L-tap kernel, delay = chunk_size - (L-1)/2 (one chunk of latency minus the
+ * look-ahead d of the kept slice, EffectFFTFilter.py:22-25).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct adsp_exact adsp_exact; /* opaque */
+typedef struct adsp_exact_config {
+    int device_id;
+    int chunk_size;    /* N: any positive length */
+    int n_channels;    /* 1..65535 */
+    int n_taps;
+    int delay;         /* >= 0 samples */
+    int sample_format; /* ADSP_FORMAT_F32 or ADSP_FORMAT_S16: type of the in/out batches */
+} adsp_exact_config;
+ADSP_API int adsp_exact_create(const adsp_exact_config* cfg, const double* taps, adsp_exact** out);
+ADSP_API void adsp_exact_destroy(adsp_exact* fir);
+ADSP_API int adsp_exact_reset(adsp_exact* fir); /* history back to zeros */
+/* d_in / d_out: device [n_steps][n_channels][chunk_size], NOT aliased; asynchronous on `stream` */
+ADSP_API int adsp_exact_apply_device(adsp_exact* fir, const void* d_in, void* d_out, int n_steps, void* stream);
+ADSP_API int adsp_exact_apply_host(adsp_exact* fir, const void* in, void* out, int n_steps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,11 @@ class AdspScanConfig(ctypes.Structure):
                 ("kind", ctypes.c_int), ("n_sections", ctypes.c_int)]
 
 
+class AdspExactConfig(ctypes.Structure):
+    _fields_ = [("device_id", ctypes.c_int), ("chunk_size", ctypes.c_int), ("n_channels", ctypes.c_int),
+                ("n_taps", ctypes.c_int), ("delay", ctypes.c_int), ("sample_format", ctypes.c_int)]
+
+
 _c_int_p = ctypes.POINTER(ctypes.c_int)
 _c_float_p = ctypes.POINTER(ctypes.c_float)
 _engine_p = ctypes.c_void_p
@@ -89,6 +94,11 @@ SIGNATURES = {
     "adsp_delay_history_chunks": (ctypes.c_int, [ctypes.c_void_p, _c_int_p]),
     "adsp_delay_apply_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "adsp_delay_apply_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    "adsp_exact_create": (ctypes.c_int, [ctypes.POINTER(AdspExactConfig), ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "adsp_exact_destroy": (None, [ctypes.c_void_p]),
+    "adsp_exact_reset": (ctypes.c_int, [ctypes.c_void_p]),
+    "adsp_exact_apply_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "adsp_exact_apply_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "adsp_reset": (ctypes.c_int, [_engine_p]),
     "adsp_apply_host": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "adsp_apply_device": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),

@@ -31,6 +31,8 @@ def init_process_group(backend=None):
         return dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("RANK", "0")        # a single process outside torchrun is a world of one
+    os.environ.setdefault("WORLD_SIZE", "1")
     if backend is None:
         import torch
         backend = "nccl" if torch.cuda.is_available() else "gloo"

@@ -165,6 +165,56 @@ class FirEngine:
         _capi.check(self._lib.adsp_synchronize(self._h, _ptr(stream)))
 
 
+class ExactFirEngine:
+    """Exact mode (adsp_exact_*): the same streaming FIR as a float64 direct sum on the GPU.  For int16 PCM it applies
+    the reference's conversions to the letter and returns the int16 stream the reference writes (Utility.py:236-237,
+    :306) - what the float32 FFT engines can only do to within one LSB, because the export truncates; for float32 it
+    is the on-device ground truth of the parity tests.  O(taps) per sample: files and checks, not the hot path."""
+
+    def __init__(self, fir: FirStream, channels=1, device=0, sample_format="f32"):
+        self._lib = _capi.load()
+        self._h = ctypes.c_void_p(None)
+        if sample_format not in _FORMATS:
+            raise ValueError("sample_format must be 'f32' or 's16'")
+        self.fir, self.sample_format = fir, sample_format
+        code, self.dtype = _FORMATS[sample_format]
+        self.chunk_size, self.channels, self.device = int(fir.chunk_size), int(channels), int(device)
+        taps = np.ascontiguousarray(fir.taps, dtype=np.float64)
+        cfg = _capi.AdspExactConfig(self.device, self.chunk_size, self.channels, len(taps), int(fir.delay), code)
+        _capi.check(self._lib.adsp_exact_create(ctypes.byref(cfg), _ptr(taps), ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.adsp_exact_destroy(self._h)
+            self._h = ctypes.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        _capi.check(self._lib.adsp_exact_reset(self._h))
+
+    def apply_device(self, d_in, d_out, n_steps=1, stream=None):
+        """Device-resident [n_steps, C, N] buffers of the engine's sample type, not aliased; asynchronous."""
+        _capi.check(self._lib.adsp_exact_apply_device(self._h, _ptr(d_in), _ptr(d_out), int(n_steps), _ptr(stream)))
+
+    def apply_host(self, x):
+        if self.sample_format == "s16" and np.asarray(x).dtype != np.int16:
+            raise TypeError("this engine filters int16 PCM; pass an int16 array")
+        x = np.ascontiguousarray(x, dtype=self.dtype)
+        squeeze = x.ndim == 2
+        if squeeze:
+            x = x[None]
+        if x.ndim != 3 or x.shape[1:] != (self.channels, self.chunk_size):
+            raise ValueError(f"expected [steps, {self.channels}, {self.chunk_size}], got {x.shape}")
+        out = np.empty_like(x)
+        _capi.check(self._lib.adsp_exact_apply_host(self._h, _ptr(x), _ptr(out), x.shape[0]))
+        return out[0] if squeeze else out
+
+
 class PartitionedFirEngine:
     """A FIR too long for one 32768-point transform (e.g. the reference's Example4: chunk 88200, 44099 taps), run as
     P ordinary engines over the same input - one per slice of the kernel, each with the slice's extra delay - whose

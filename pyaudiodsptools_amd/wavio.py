@@ -16,7 +16,7 @@ import numpy as np
 
 from . import config
 from .design import FirStream
-from .engine import FirEngine
+from .engine import ExactFirEngine, FirEngine
 
 
 # ---- the reference's chunk plumbing ---------------------------------------------------------
@@ -119,8 +119,14 @@ class WavBank:
         """[steps, channels, chunk] int16, the engine's batch layout."""
         return np.ascontiguousarray(self.pcm.reshape(self.channels, self.steps, self.chunk_size).transpose(1, 0, 2))
 
-    def process(self, fir: FirStream, device=0):
-        eng = FirEngine(fir, channels=self.channels, device=device, sample_format="s16", optimize_for="batch")
+    def process(self, fir: FirStream, device=0, exact=False):
+        """exact=False: the int16 FFT engine (within one LSB of the reference's WAV output, a few samples per ten
+        thousand differ because the export truncates); exact=True: the float64 direct-sum engine, which reproduces the
+        reference's int16 stream bit for bit (O(taps) per sample - fine for files)."""
+        if exact:
+            eng = ExactFirEngine(fir, channels=self.channels, device=device, sample_format="s16")
+        else:
+            eng = FirEngine(fir, channels=self.channels, device=device, sample_format="s16", optimize_for="batch")
         out = eng.apply_host(self.batch())  # [steps, C, N] int16
         eng.close()
         flat = out.transpose(1, 0, 2).reshape(self.channels, -1)

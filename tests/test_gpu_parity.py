@@ -339,6 +339,22 @@ def test_errors_cross_the_abi_as_exceptions(adsp):
 
 
 # ---- BASELINE.json full sizes: properties that do not need the oracle at full size --------------
+def assert_all_channels_match_exact(adsp, fir, x, y, what):
+    """EVERY output sample of a full-size batch against the float64 direct sum computed on the GPU (adsp_exact_*, itself
+    pinned to the oracle's direct_stream_convolution by tests/test_gpu_pcm16.py): the 1e-5 tolerance of BASELINE.md 3."""
+    import torch
+    ex = adsp.ExactFirEngine(fir, channels=x.shape[1])
+    truth = torch.empty_like(x)
+    ex.apply_device(x, truth, x.shape[0], torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    scale = float(truth.abs().max())
+    err = float((y - truth).abs().max())
+    assert scale > 0.1 and err <= 1e-5 * scale, f"{what}: max|d| = {err:.3e} over all channels, scale {scale:.3e}"
+    assert torch.allclose(y, truth, rtol=1e-5, atol=1e-6 * max(scale, 1.0)), f"{what}: allclose failed"
+    ex.close()
+
+
+
 def test_config2_full_size_properties(adsp):
     """4096 channels x 4096 samples, LowCut(800): impulse response == taps, linearity, and a sampled
     oracle check, through the device-pointer path."""
@@ -371,6 +387,7 @@ def test_config2_full_size_properties(adsp):
     for c in (2, 1777, channels - 1):
         truth = o.direct_stream_convolution(taps, xh[:, c].reshape(-1), n)
         assert_parity(yh[:, c].reshape(-1), truth, what=f"config2 ch {c}")
+    assert_all_channels_match_exact(adsp, dev.fir, x, y, "config2")
     # linearity / channel independence: filter(a*x + b*z) == a*filter(x) + b*filter(z), in one multi-step launch
     eng.reset()
     z = torch.empty_like(x).uniform_(-1, 1, generator=g)
@@ -437,6 +454,7 @@ def test_config4_full_size_properties(adsp):
     xh = x.cpu().numpy()
     for c in (2, 4097, channels - 1):
         assert_parity(yh[:, c].reshape(-1), o.direct_stream_convolution(taps, xh[:, c].reshape(-1), n), what=f"config4 ch {c}")
+    assert_all_channels_match_exact(adsp, dev.fir, x, y, "config4")
     eng.reset()
     y_all = torch.empty_like(x)
     eng.apply_device(x, y_all, steps, s)  # one launch, 1.5 N kept per transform
@@ -487,6 +505,7 @@ def test_config5_full_size_properties(adsp):
     for c in (2, 2049, channels - 1):
         truth = o.direct_stream_convolution(taps, xh[:, c].reshape(-1), n, chain.latency_chunks, chain.lookahead)
         assert_parity(yh[:, c].reshape(-1), truth, what=f"config5 ch {c}")
+    assert_all_channels_match_exact(adsp, chain, x, y, "config5")  # against ALL 16377 taps, every channel
     # streaming (one launch per chunk) == the multi-step launch
     eng.reset()
     y_s = torch.empty_like(x)

@@ -64,6 +64,57 @@ def test_example2_stereo_through_wavbank(adsp, tmp_path):
         assert (w.getnchannels(), w.getframerate(), w.getnframes()) == (2, 44100, 4 * 4096)
 
 
+def test_exact_mode_is_bit_identical_to_the_reference_int16_stream(adsp, golden, tmp_path):
+    """SURVEY 8f.1 'bit-for-bit at the int16 level': the float64 direct-sum engine (adsp_exact_*) with the reference's
+    conversions reproduces (reference_out * 32767).astype(int16) exactly on the Example1 and Example2 fixtures."""
+    from pyaudiodsptools_amd import ExactFirEngine, FirStream, design
+    fir = FirStream(design.lowcut_kernel(800, 44100, 4096), 4096)
+    g = golden["kat_example1"]
+    pcm = g["pcm16_first8"]
+    want = orc().float_to_pcm16(g["out_first8"])
+    eng = ExactFirEngine(fir, channels=1, sample_format="s16")
+    stream = np.concatenate([eng.apply_host(pcm[i * 4096:(i + 1) * 4096].reshape(1, 4096))[0] for i in range(8)])
+    assert stream.dtype == np.int16 and np.array_equal(stream, want), int((stream != want).sum())
+    eng.reset()
+    assert np.array_equal(eng.apply_host(pcm.reshape(8, 1, 4096)).reshape(-1), want)
+    # Example2 (stereo = two devices) through the file front end
+    g2 = np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_example2.npz"))
+    with wave.open(str(tmp_path / "in.wav"), "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(44100); w.writeframes(g2["pcm16_first4_stereo"].tobytes())
+    adsp.config.initialize(44100, 4096)
+    out = adsp.WavBank([str(tmp_path / "in.wav")]).process(fir, exact=True)[0]
+    assert np.array_equal(out[:, 0], orc().float_to_pcm16(g2["out_left"]))
+    assert np.array_equal(out[:, 1], orc().float_to_pcm16(g2["out_right"]))
+
+
+def test_exact_mode_float32_is_the_correctly_rounded_direct_convolution(adsp):
+    """float32 batches: float32(float64 direct sum) - equal to the oracle's float64 convolution rounded once, for a cut
+    filter, the EQ composite and the three-device chain, ragged channels, stream and multi-step, chunk sizes that are
+    no power of two included."""
+    from pyaudiodsptools_amd import ExactFirEngine, FirStream, design
+    o = orc()
+    for n, channels, kind in [(512, 3, "eq"), (1000, 2, "lowcut"), (256, 5, "chain"), (4096, 2, "lowcut")]:
+        fs, steps = 44100, 5
+        lc = FirStream(design.lowcut_kernel(300, fs, n), n)
+        eq = FirStream(design.eq3_composite(100, 2, 700, -4, 8000, 5, fs, n), n)
+        hc = FirStream(design.highcut_kernel(6000, fs, n), n)
+        fir = {"lowcut": lc, "eq": eq, "chain": lc.then(eq).then(hc)}[kind]
+        x = np.random.default_rng(n).uniform(-1, 1, (steps, channels, n)).astype(np.float32)
+        eng = ExactFirEngine(fir, channels=channels)
+        y_stream = np.stack([eng.apply_host(x[k]) for k in range(steps)])
+        eng.reset()
+        y_batch = eng.apply_host(x)
+        assert np.array_equal(y_stream, y_batch)
+        for c in range(channels):
+            truth = o.direct_stream_convolution(fir.taps, x[:, c].reshape(-1), n, fir.latency_chunks, fir.lookahead)
+            got = y_batch[:, c].reshape(-1)
+            # the two float64 sums differ in their order of additions (1e-16): at most a float32 ulp, almost always none
+            assert np.abs(got - truth).max() <= 1.3e-7 * np.abs(truth).max()
+            assert (got == truth.astype(np.float32)).mean() > 0.999
+    with pytest.raises(RuntimeError):
+        ExactFirEngine(FirStream(np.ones(3), 64, latency_chunks=0, lookahead=5))  # negative delay: needs future input
+
+
 @pytest.mark.parametrize("n,channels,kind", [(64, 19, "lowcut"), (256, 5, "chain"), (512, 6, "eq"), (1024, 3, "lowcut"),
                                              (2048, 2, "eq"), (4096, 5, "lowcut"), (4096, 2, "chain"), (8192, 2, "eq")])
 def test_random_pcm_vs_oracle(adsp, n, channels, kind):
