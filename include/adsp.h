@@ -119,7 +119,14 @@ ADSP_API int adsp_destroy(adsp_engine* engine);
  * again at any time to change the filter (takes effect for the next apply). */
 ADSP_API int adsp_set_spectrum(adsp_engine* engine, const float* spectrum_interleaved, int n_bins);
 
-/* Same, from device memory (e.g. after an RCCL broadcast). */
+/* The same filter change in a LIVE stream: the tables are staged in pinned memory and copied on `stream`, so launches
+ * already queued there finish with the old filter, later ones use the new one, and nothing else is waited for (no
+ * device-wide synchronisation; adsp_set_spectrum drains the device and is meant for set-up).  Launches that follow on
+ * OTHER streams must be ordered after `stream` by the caller. */
+ADSP_API int adsp_set_spectrum_async(adsp_engine* engine, const float* spectrum_interleaved, int n_bins, void* stream);
+
+/* Same, from device memory (e.g. after an RCCL broadcast enqueued on `stream`): waits for `stream` only - the tables are
+ * float64 host arithmetic, so the spectrum makes one trip to the host - then updates them stream-ordered as above. */
 ADSP_API int adsp_set_spectrum_device(adsp_engine* engine, const float* d_spectrum_interleaved, int n_bins, void* stream);
 
 /* 1 when the spectrum last set is real (every imaginary part exactly 0 - a symmetric kernel centred on circular index

@@ -63,6 +63,7 @@ SIGNATURES = {
     "adsp_create": (ctypes.c_int, [ctypes.POINTER(AdspConfig), ctypes.POINTER(_engine_p)]),
     "adsp_destroy": (ctypes.c_int, [_engine_p]),
     "adsp_set_spectrum": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_int]),
+    "adsp_set_spectrum_async": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "adsp_set_spectrum_device": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "adsp_set_kernel_reach": (ctypes.c_int, [_engine_p, ctypes.c_int]),
     "adsp_set_block_outputs": (ctypes.c_int, [_engine_p, ctypes.c_int]),

@@ -233,6 +233,12 @@ struct adsp_engine {
     char* zeros;   // 4*chunk_size zero bytes
     bool have_spectrum;
     bool real_spec;  // every Im H == 0: the kernel takes the 3-real-constants-per-pair path
+    // stream-ordered table updates (adsp_set_spectrum_async): two pinned staging buffers, reused alternately
+    char* pin_tab[2];
+    size_t pin_tab_bytes;
+    hipEvent_t ev_tab[2];
+    bool tab_busy[2];
+    int tab_slot;
     int kernel_reach;  // kernel taps at negative circular indices (adsp_set_kernel_reach); < 0 = unknown: load the whole window
     char* stage_in;
     char* stage_out;
@@ -266,7 +272,10 @@ int set_device(const adsp_engine* e) {
     return ADSP_OK;
 }
 
-int upload_pairs(adsp_engine* e, const float* H, hipStream_t stream) {
+// async = false: blocking copies (the caller has drained the device: nothing is reading the tables).
+// async = true : the tables are staged in pinned memory and copied ON `stream`, i.e. after every launch already queued
+//                there and before every later one - no device-wide synchronisation, the filter changes between two steps.
+int upload_pairs(adsp_engine* e, const float* H, hipStream_t stream, bool async = false) {
     const PlanInfo& pl = *e->plan;
     const int M = e->M, T = pl.T;
     const int R = pl.XL ? pl.P : pl.P / 2;   // radix of the paired passes
@@ -320,10 +329,29 @@ int upload_pairs(adsp_engine* e, const float* H, hipStream_t stream) {
     put0(1, M / 2);
     for (int r = 1; r < R / 2; ++r) put0(2 + (r - 1), D * r);
     for (int r = 0; r < R / 2; ++r) put0(2 + (R / 2 - 1) + r, D / 2 + D * r);
-    // synchronous copies from pageable memory: safe to free the vectors on return
-    HIP_TRY(hipStreamSynchronize(stream));
-    HIP_TRY(hipMemcpy(e->pair, tab.data(), tab.size() * sizeof(float4), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->pair0, tab0.data(), tab0.size() * sizeof(float2), hipMemcpyHostToDevice));
+    const size_t b1 = tab.size() * sizeof(float4), b0 = tab0.size() * sizeof(float2);
+    if (async) {
+        if (!e->pin_tab[0]) {
+            for (int i = 0; i < 2; ++i) {
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->pin_tab[i]), b1 + b0, hipHostMallocDefault));
+                HIP_TRY(hipEventCreateWithFlags(&e->ev_tab[i], hipEventDisableTiming));
+            }
+            e->pin_tab_bytes = b1 + b0;
+        }
+        const int b = e->tab_slot ^= 1;
+        if (e->tab_busy[b]) HIP_TRY(hipEventSynchronize(e->ev_tab[b]));  // the copy two updates ago read this buffer
+        memcpy(e->pin_tab[b], tab.data(), b1);
+        memcpy(e->pin_tab[b] + b1, tab0.data(), b0);
+        HIP_TRY(hipMemcpyAsync(e->pair, e->pin_tab[b], b1, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(e->pair0, e->pin_tab[b] + b1, b0, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(e->ev_tab[b], stream));
+        e->tab_busy[b] = true;
+    } else {
+        // synchronous copies from pageable memory: safe to free the vectors on return
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(e->pair, tab.data(), b1, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->pair0, tab0.data(), b0, hipMemcpyHostToDevice));
+    }
     e->have_spectrum = true;
     return ADSP_OK;
 }
@@ -508,6 +536,11 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     e->have_spectrum = false;
     e->real_spec = false;
     e->kernel_reach = -1;
+    e->pin_tab[0] = e->pin_tab[1] = nullptr;
+    e->pin_tab_bytes = 0;
+    e->ev_tab[0] = e->ev_tab[1] = nullptr;
+    e->tab_busy[0] = e->tab_busy[1] = false;
+    e->tab_slot = 0;
     e->stage_in = e->stage_out = nullptr;
     e->stage_elems = 0;
     e->pin_in[0] = e->pin_in[1] = e->pin_out = nullptr;
@@ -564,8 +597,10 @@ int adsp_destroy(adsp_engine* e) {
     if (e->ev_copy_done) (void)hipEventDestroy(e->ev_copy_done);
     if (e->stage_in) (void)hipFree(e->stage_in);
     if (e->stage_out) (void)hipFree(e->stage_out);
-    for (char* p : {e->pin_in[0], e->pin_in[1], e->pin_out})
+    for (char* p : {e->pin_in[0], e->pin_in[1], e->pin_out, e->pin_tab[0], e->pin_tab[1]})
         if (p) (void)hipHostFree(p);
+    for (hipEvent_t ev : {e->ev_tab[0], e->ev_tab[1]})
+        if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : {e->ev_pin[0], e->ev_pin[1], e->ev_kernel})
         if (ev) (void)hipEventDestroy(ev);
     for (auto& v : {&e->timed, &e->free_ev})
@@ -586,16 +621,25 @@ int adsp_set_spectrum(adsp_engine* e, const float* spectrum, int n_bins) {
     return upload_pairs(e, spectrum, nullptr);
 }
 
+int adsp_set_spectrum_async(adsp_engine* e, const float* spectrum, int n_bins, void* stream) {
+    if (!e || !spectrum) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (n_bins != e->M + 1) return fail(ADSP_ERR_ARG, "n_bins %d != fft_size/2+1 = %d", n_bins, e->M + 1);
+    int rc = set_device(e);
+    if (rc) return rc;
+    return upload_pairs(e, spectrum, (hipStream_t)stream, true);
+}
+
 int adsp_set_spectrum_device(adsp_engine* e, const float* d_spectrum, int n_bins, void* stream) {
     if (!e || !d_spectrum) return fail(ADSP_ERR_ARG, "NULL argument");
     if (n_bins != e->M + 1) return fail(ADSP_ERR_ARG, "n_bins %d != fft_size/2+1 = %d", n_bins, e->M + 1);
     int rc = set_device(e);
     if (rc) return rc;
+    // the pair tables are float64 host arithmetic: fetch the spectrum ON `stream` (ordered after whatever produced it,
+    // e.g. an RCCL broadcast enqueued there), wait for that stream only, then update the tables stream-ordered
     std::vector<float> host((size_t)2 * n_bins);
+    HIP_TRY(hipMemcpyAsync(host.data(), d_spectrum, host.size() * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    HIP_TRY(hipMemcpy(host.data(), d_spectrum, host.size() * sizeof(float), hipMemcpyDeviceToHost));
-    HIP_TRY(hipDeviceSynchronize());
-    return upload_pairs(e, host.data(), nullptr);
+    return upload_pairs(e, host.data(), (hipStream_t)stream, true);
 }
 
 int adsp_spectrum_is_real(const adsp_engine* e, int* is_real) {

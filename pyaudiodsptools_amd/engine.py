@@ -68,14 +68,19 @@ class FirEngine:
             pass
 
     # -- filter -------------------------------------------------------------------------------
-    def set_fir(self, fir: FirStream):
-        """Change the filter without touching the history (same geometry required)."""
+    def set_fir(self, fir: FirStream, stream=None, live=False):
+        """Change the filter without touching the history (same geometry required).  live=True: stream-ordered
+        (adsp_set_spectrum_async) - steps already queued on `stream` finish with the old filter, later ones use the new
+        one, nothing is synchronised; otherwise the device is drained first (set-up path)."""
         geo = overlap_save_geometry(fir, self.fft_mult, self.optimize_for)
-        if geo != self.geometry:
+        if getattr(self, "geometry", geo) != geo:
             raise ValueError("new filter needs a different transform geometry; create a new engine")
         self.fir = fir
         self.spectrum = engine_spectrum(fir, geo, self.gain)
-        self.upload_spectrum(self.spectrum)
+        if live:
+            _capi.check(self._lib.adsp_set_spectrum_async(self._h, _ptr(self.spectrum), self.spectrum.size // 2, _ptr(stream)))
+        else:
+            self.upload_spectrum(self.spectrum)
         # taps at negative circular indices: lets the kernel skip the part of the window that feeds discarded outputs
         _capi.check(self._lib.adsp_set_kernel_reach(self._h, max(0, -geo.shift)))
 

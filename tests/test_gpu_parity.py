@@ -307,7 +307,11 @@ def test_device_pointer_and_ring_paths(adsp):
     assert_parity(y2.cpu().numpy(), ref, what="ring path")
 
 
-def test_spectrum_update_keeps_history(adsp):
+@pytest.mark.parametrize("live", [False, True])
+def test_spectrum_update_keeps_history(adsp, live):
+    """Filter change between two steps: adsp_set_spectrum (drains the device) and adsp_set_spectrum_async (stream-ordered,
+    no synchronisation: steps queued before it use the old filter, steps queued after it the new one)."""
+    import torch
     n, channels = 512, 3
     adsp.config.initialize(44100, n)
     from pyaudiodsptools_amd import FirStream, design
@@ -315,12 +319,22 @@ def test_spectrum_update_keeps_history(adsp):
     rng = np.random.default_rng(9)
     x = rng.uniform(-1, 1, (6, channels, n)).astype(np.float32)
     dev = adsp.CreateLowCutFilter(200, channels=channels)
-    dev.apply_batch(x[:3])
     new_taps = design.lowcut_kernel(1000, 44100, n)
-    dev.engine.set_fir(FirStream(new_taps, n))
-    y = dev.apply_batch(x[3:])
-    truth = np.stack([o.direct_stream_convolution(new_taps, x[:, c].reshape(-1), n)[3 * n:] for c in range(channels)])
-    assert_parity(y.transpose(1, 0, 2).reshape(channels, -1), truth, what="after set_fir")
+    old_taps = design.lowcut_kernel(200, 44100, n)
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.empty_like(xd)
+    s = torch.cuda.current_stream().cuda_stream
+    for k in range(3):
+        dev.engine.apply_device(xd[k], yd[k], 1, s)
+    dev.engine.set_fir(FirStream(new_taps, n), stream=s, live=live)  # no host synchronisation in between when live
+    for k in range(3, 6):
+        dev.engine.apply_device(xd[k], yd[k], 1, s)
+    torch.cuda.synchronize()
+    y = yd.cpu().numpy()
+    before = np.stack([o.direct_stream_convolution(old_taps, x[:, c].reshape(-1), n)[:3 * n] for c in range(channels)])
+    after = np.stack([o.direct_stream_convolution(new_taps, x[:, c].reshape(-1), n)[3 * n:] for c in range(channels)])
+    assert_parity(y[:3].transpose(1, 0, 2).reshape(channels, -1), before, what="before the filter change")
+    assert_parity(y[3:].transpose(1, 0, 2).reshape(channels, -1), after, what="after set_fir")
 
 
 def test_errors_cross_the_abi_as_exceptions(adsp):
