@@ -106,7 +106,9 @@ def cpu_baseline(args):
     return {"value": m["literal3n_allcores"], "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": f"oracle restatement of the reference's apply (literal 3N complex fft/ifft, numpy {m['numpy']}), one process per "
                       f"physical core over disjoint channels, {args.cpu_seconds:.0f} s per process, chunks of {args.chunk} samples; "
-                      f"{m['cpu_model']}, {cores} physical cores / {m['logical_cpus']} logical",
+                      f"{m['cpu_model']}, {cores} physical cores / {m['logical_cpus']} logical"
+                      + (f", container CPU quota {m['cgroup_cpu_quota']:.1f} CPUs" if m.get("cgroup_cpu_quota") else "")
+                      + (f", load average before the run {m['loadavg_before']:.1f}" if "loadavg_before" in m else ""),
             "variants_msamples_s": {"literal_3n_complex_1_process": m["literal3n_1proc"],
                                     f"literal_3n_complex_{cores}_processes": m["literal3n_allcores"],
                                     "rfft_2n_1_process_16ch_batches": m["rfft2n_1proc"],
@@ -397,6 +399,12 @@ def main():
             line["latency"] = latency
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
+        sys.stdout.flush()
+        try:  # RCCL prints a version banner through C stdio: push it out BEFORE the one JSON line, not after it at exit
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(line), flush=True)
     if barrier is not None:
         tdist.barrier()

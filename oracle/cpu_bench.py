@@ -38,6 +38,21 @@ def physical_cores():
     return len(pairs) if pairs else max(1, len(allowed) // 2)
 
 
+def cpu_quota():
+    """CPUs the container may actually use at once (cgroup v2 cpu.max / v1 cfs quota); None when unlimited."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as fh:
@@ -98,7 +113,15 @@ def run_worker(job):
 def measure(filter_name, n, fs, seconds_each=5.0, rfft_channels=16):
     """All four figures in Msamples/s (None where a variant does not apply)."""
     cores = physical_cores()
-    out = {"physical_cores": cores, "logical_cpus": os.cpu_count(), "cpu_model": cpu_model(), "numpy": np.__version__}
+    quota = cpu_quota()
+    if quota:  # a container limited to q CPUs cannot run more than q processes at once, whatever /proc/cpuinfo lists
+        cores = max(1, min(cores, int(quota + 0.999)))
+    out = {"physical_cores": cores, "logical_cpus": os.cpu_count(), "cpu_model": cpu_model(), "numpy": np.__version__,
+           "cgroup_cpu_quota": quota}
+    try:
+        out["loadavg_before"] = os.getloadavg()[0]
+    except OSError:
+        pass
     ctx = mp.get_context("spawn")  # the parent holds a HIP context: never fork it
     for variant, chans in (("literal3n", 1), ("rfft2n", rfft_channels)):
         samples, el = run_worker((filter_name, variant, n, fs, chans, seconds_each, 1234))

@@ -389,8 +389,6 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
     if (total + 8LL * c.fft_size >= 0x7fffffffLL)  // the kernel indexes a channel's time axis with 32-bit ints
         return fail(ADSP_ERR_ARG, "n_steps %d x chunk %d is too long for one call; split it", n_steps, c.chunk_size);
     a.nblk = (int)((total + a.V - 1) / a.V);
-    static const int stagger_env = getenv("ADSP_STAGGER") ? atoi(getenv("ADSP_STAGGER")) : 0;  // tuning only
-    a.stagger = n_steps == 1 ? stagger_env : 0;
     // window positions >= out_offset + V + reach feed discarded outputs only: whole register pairs (4T samples) beyond
     // them are not fetched
     a.win_pairs = pl.P / 2;

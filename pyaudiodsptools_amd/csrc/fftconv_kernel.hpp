@@ -88,7 +88,6 @@ struct KernelArgs {
     int win_pairs;         // register PAIRS of the window that are loaded (P/2 = all); the rest is taken as zero: window
                            // positions >= out_offset + V + (kernel taps at negative circular indices) only feed discarded
                            // outputs - a single-step launch of a zero-phase cut filter needs 1.5 N of its 2 N window
-    int stagger;           // tuning: first-generation workgroups of a launch start (slot on their CU) x stagger x 0.4 us late
     int accumulate;        // 1: add the kept samples to what `out` holds (partitioned FIRs, mixing); 2: and clip the sum
                            // to [-1, 1] (MixSignals).  Plain kernels: generic geometry + mode 1 only; EPI kernels: all.
 };
@@ -1029,9 +1028,6 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(con
     if (cg >= a.ncg) return;  // whole workgroup leaves together
     const int c = cg * CPB + grp;
     const bool chan_ok = CPB == 1 ? true : (c < a.C);
-    if (a.stagger > 0 && idx < 128) {  // tuning: keep the co-resident workgroups of a short launch out of lock step
-        for (int i = ((idx >> 5) & 3) * a.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(16);
-    }
 
     const int o = blk * a.V;        // first output-time of this block (multiple of N/4)
     const int t0 = o - a.lookback;  // first input-time of the window (multiple of N/4)

@@ -9,9 +9,6 @@ const PlanInfo kVariants[] = {
     make_plan<Plan<16384, 32, 4, 32, 2, 16, 16>, 1, 4, false, false>(),      // 1: the former four-pass plan (-6 %)
     make_plan<Plan<16384, 16, 4, 4, 16, 16, 16, true>, 1, 4, false, false>(),  // 2: XL, 1024 threads, 16 points per thread
     make_plan<Plan<16384, 16, 4, 16, 4, 16, 16, true>, 1, 4, false, false>(),  // 3: same, radix 4 second
-    make_plan<Plan<512, 8, 3, 8, 8, 8, 1, true>, 1, 2, false, false>(),        // 4: XL, one wave per transform, 8 points per thread
-    make_plan<Plan<512, 8, 3, 8, 8, 8, 1, true>, 4, 2, false, false>(),        // 5: same, four transforms per workgroup
-    make_plan<Plan<1024, 16, 3, 4, 16, 16, 1, true>, 1, 2, false, false>(),    // 6: XL M = 1024, one wave per transform
 };
 }  // namespace
 

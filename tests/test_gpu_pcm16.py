@@ -23,7 +23,10 @@ def orc():
     return o
 
 
-def assert_pcm_parity(got, ref, what, max_mismatch=0.03):
+def assert_pcm_parity(got, ref, what, max_mismatch=0.005):
+    """float32 FFT engine vs the reference's int16 export: never more than one LSB, and rarely (measured on MI355X,
+    profiles/r2_pcm16_histogram.json: 0.02 % of the Example1 samples, 0.22 % at full scale; +1 and -1 equally often).
+    The bound leaves a factor 2 over the worst case measured."""
     got, ref = np.asarray(got, np.int32), np.asarray(ref, np.int32)
     assert got.shape == ref.shape, what
     diff = np.abs(got - ref)
@@ -83,8 +86,20 @@ def test_exact_mode_is_bit_identical_to_the_reference_int16_stream(adsp, golden,
         w.setnchannels(2); w.setsampwidth(2); w.setframerate(44100); w.writeframes(g2["pcm16_first4_stereo"].tobytes())
     adsp.config.initialize(44100, 4096)
     out = adsp.WavBank([str(tmp_path / "in.wav")]).process(fir, exact=True)[0]
-    assert np.array_equal(out[:, 0], orc().float_to_pcm16(g2["out_left"]))
-    assert np.array_equal(out[:, 1], orc().float_to_pcm16(g2["out_right"]))
+    # The exact engine returns the int16 stream of the EXACT convolution.  The reference's own pipeline (complex64
+    # forward FFT under numpy >= 2) is within ~4e-9 of it, so the two can only disagree where exact * 32767 sits closer
+    # than that to an integer: one sample of these 32768 (left channel, y * 32767 = -2267.99998 exact, -2268.00012 in
+    # the reference).  Everything else must be identical, and every disagreement must be such a boundary case.
+    pcm2 = g2["pcm16_first4_stereo"].reshape(-1, 2)
+    for ch, key in ((0, "out_left"), (1, "out_right")):
+        want2 = orc().float_to_pcm16(g2[key])
+        bad = np.nonzero(out[:, ch] != want2)[0]
+        assert len(bad) <= 1, (key, bad)
+        if len(bad):
+            y64 = orc().direct_stream_convolution(fir.taps, orc().pcm16_to_float(pcm2[:, ch]), 4096)
+            v = y64[bad] * 32767
+            assert np.abs(v - np.round(v)).max() < 1e-3 and np.abs(out[bad, ch].astype(int) - want2[bad]).max() == 1
+            assert np.array_equal(out[:, ch], orc().float_to_pcm16(y64.astype(np.float32)))  # == the exact stream
 
 
 def test_exact_mode_float32_is_the_correctly_rounded_direct_convolution(adsp):
@@ -136,8 +151,8 @@ def test_random_pcm_vs_oracle(adsp, n, channels, kind):
         x = o.pcm16_to_float(pcm[:, c].reshape(-1))
         truth = o.direct_stream_convolution(fir.taps, x, n, latency_chunks=fir.latency_chunks, lookahead=fir.lookahead)
         want = o.float_to_pcm16(truth.astype(np.float32))
-        assert_pcm_parity(y_stream[:, c].reshape(-1), want, f"{kind} N={n} ch={c} stream", max_mismatch=0.05)
-        assert_pcm_parity(y_batch[:, c].reshape(-1), want, f"{kind} N={n} ch={c} batch", max_mismatch=0.05)
+        assert_pcm_parity(y_stream[:, c].reshape(-1), want, f"{kind} N={n} ch={c} stream", max_mismatch=0.01)
+        assert_pcm_parity(y_batch[:, c].reshape(-1), want, f"{kind} N={n} ch={c} batch", max_mismatch=0.01)
 
 
 def test_int16_state_and_device_path(adsp):
