@@ -30,8 +30,8 @@
 //    a dwordx2 costs the TA exactly what a dwordx4 does; chunk selection (ring history vs. the new batch)
 //    is resolved once per block into <= F/N + 1 pointers; output stores are non-temporal.
 //  * no packed f32 math (half rate on gfx950), no MFMA (no contraction): ~100 flop/sample against
-//    8-10 B/sample; sustained multi-step launches are power-limited (clock ~1.7 GHz), single-step
-//    launches latency-bound at 2.45 GHz.
+//    8-10 B/sample; sustained multi-step launches run at 1.9-2.0 GHz (power controller), single-step launches at
+//    2.5-2.6 GHz (the chip idles between them) - DESIGN.md section 5.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
