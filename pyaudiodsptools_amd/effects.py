@@ -27,8 +27,15 @@ class Effect:
         return (0.0, 0.0, 0.0)
 
     def _phase(self, n_samples):
-        """LFO table index of the first sample of the next n_samples (effects with a time base only)."""
+        """LFO table index of the first sample of the next n_samples (effects with a time base only); advances the
+        time base.  `_peek_phase` / `_commit_phase` split it so that a failed call leaves the time base where it was."""
         return 0
+
+    def _peek_phase(self, n_samples):
+        return 0, None
+
+    def _commit_phase(self, token):
+        pass
 
     def apply(self, float_array_input, device=0, stream=None):
         """numpy array / list -> fresh float32 numpy array of the same shape; a torch CUDA tensor -> fresh CUDA tensor."""
@@ -39,15 +46,19 @@ class Effect:
             if str(x.dtype) != "torch.float32" or not x.is_cuda or not x.is_contiguous():
                 raise TypeError("device input must be a contiguous float32 CUDA tensor")
             y = x.new_empty(x.shape)
-            _capi.check(lib.adsp_effect_device(x.device.index or 0, self.op, p0, p1, p2, self._phase(x.numel()),
+            phase, token = self._peek_phase(x.numel())
+            _capi.check(lib.adsp_effect_device(x.device.index or 0, self.op, p0, p1, p2, phase,
                                                ctypes.c_void_p(x.data_ptr()),
                                                ctypes.c_void_p(y.data_ptr()), x.numel(),
                                                ctypes.c_void_p(stream) if stream else None))
+            self._commit_phase(token)  # only a call that went through moves the LFO
             return y
         x = np.ascontiguousarray(float_array_input, dtype=np.float32)
         y = np.empty_like(x)
-        _capi.check(lib.adsp_effect_host(int(device), self.op, p0, p1, p2, self._phase(x.size), ctypes.c_void_p(x.ctypes.data),
+        phase, token = self._peek_phase(x.size)
+        _capi.check(lib.adsp_effect_host(int(device), self.op, p0, p1, p2, phase, ctypes.c_void_p(x.ctypes.data),
                                          ctypes.c_void_p(y.ctypes.data), x.size))
+        self._commit_phase(token)
         return y
 
 
@@ -151,12 +162,21 @@ class CreateTremolo(Effect):
     def params(self):
         return (self.tremolo_depth, self.lfo_in_hertz / self.sin_sample_rate, float(self.lfo_length))
 
+    def _peek_phase(self, n_samples):
+        buffered = self._buffered
+        if buffered < n_samples:  # whole tables are appended until the buffer covers the chunk
+            buffered += -(-(n_samples - buffered) // self.lfo_length) * self.lfo_length
+        phase = (-buffered) % self.lfo_length
+        if buffered != n_samples:  # the reference's copy[-0:] keeps everything in that one case
+            buffered -= n_samples
+        return phase, buffered
+
+    def _commit_phase(self, token):
+        self._buffered = token
+
     def _phase(self, n_samples):
-        if self._buffered < n_samples:  # whole tables are appended until the buffer covers the chunk
-            self._buffered += -(-(n_samples - self._buffered) // self.lfo_length) * self.lfo_length
-        phase = (-self._buffered) % self.lfo_length
-        if self._buffered != n_samples:  # the reference's copy[-0:] keeps everything in that one case
-            self._buffered -= n_samples
+        phase, token = self._peek_phase(n_samples)
+        self._commit_phase(token)
         return phase
 
     def apply(self, float_array_input, device=0, stream=None):

@@ -113,8 +113,11 @@ def test_fused_hard_distortion_away_from_its_discontinuities(adsp, golden):
     x = seeded_stream(101, chunks * n)
     pre = np.concatenate([plain.apply(x[i * n:(i + 1) * n]) for i in range(chunks)])
     got = np.concatenate([fused.apply(x[i * n:(i + 1) * n]) for i in range(chunks)])
+    # the distortion jumps at x = 0 (0 -> +0.951) and at |x| = 0.8: a filter output within 1e-4 of either may land on the
+    # other side of the jump than the reference's; those samples are masked and counted: the first chunk (the filter's
+    # response to its zero history, |y| < 1e-4 almost everywhere) and 2 of the 3584 samples after it
     safe = (np.abs(pre) > 1e-4) & (np.abs(np.abs(pre) - 0.8) > 1e-4)
-    assert safe.mean() > 0.85
+    assert (~safe)[n:].sum() <= 4 and (~safe)[:n].sum() >= 400, (int((~safe)[:n].sum()), int((~safe)[n:].sum()))  # measured: 416 and 2
     assert_parity(got[safe], golden["kat_effects"]["chain512_highcut_harddist"][safe])
     assert np.abs(got).max() <= 1.0
 
