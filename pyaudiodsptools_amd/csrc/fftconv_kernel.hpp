@@ -98,10 +98,15 @@ struct KernelArgs {
 // ------------------------------------------------------------------------------------------
 // XL_ = cross-lane pairing: every pass has ONE butterfly per thread (last radix == P) and the real-FFT
 // partner of lane l lives in lane l ^ 32 of the same wave (needs T % 64 == 0).
-template <int M_, int P_, int NP_, int A0, int A1, int A2, int A3, bool XL_ = false>
+// HALF_ = every LDS exchange runs in two rounds over HALF the buffer (elements < M/2, then the rest): 4 M bytes of LDS per
+// transform instead of 8 M, two more barriers per exchange - for the large transforms, whose LDS footprint is what keeps
+// a second or third workgroup off the CU.  MINW_ = waves per SIMD the register allocation must leave room for.
+template <int M_, int P_, int NP_, int A0, int A1, int A2, int A3, bool XL_ = false, bool HALF_ = false, int MINW_ = ADSP_MIN_WAVES>
 struct Plan {
     static constexpr int M = M_, P = P_, NP = NP_, T = M_ / P_;
-    static constexpr bool XL = XL_;
+    static constexpr bool XL = XL_, HALF = HALF_;
+    static constexpr int MINW = MINW_;
+    static constexpr int LDS_ELEMS = HALF_ ? M_ / 2 : M_;
     static constexpr int fwd(int p) { return p == 0 ? A0 : p == 1 ? A1 : p == 2 ? A2 : A3; }
     static constexpr int inv(int p) { return fwd(NP_ - 1 - p); }
     static constexpr int rad(bool inverse, int p) { return inverse ? inv(p) : fwd(p); }
@@ -140,6 +145,7 @@ struct Plan {
     static_assert(fwd(NP_ - 1) == RL, "last forward radix must be P/2 (two butterflies per thread), or P for XL plans");
     static_assert(!XL_ || (M_ / P_) % 64 == 0, "XL plans need whole waves");
     static_assert(stride(false, NP_) == M_, "radices must multiply to M");
+    static_assert(!HALF_ || M_ >= 2048, "half-buffer exchanges: the swizzle must stay below bit log2(M) - 1");
 };
 
 // ------------------------------------------------------------------------------------------
@@ -379,6 +385,50 @@ struct Pass {
         }
     }
 
+    // half-buffer rounds (Plan::HALF): round H moves the elements whose index has top bit H through lds[0 .. M/2).
+    // A butterfly's outputs all share that bit (it is the top bit of j_hi), so a round is whole butterflies.
+    template <int H>
+    static __device__ __forceinline__ void write_half(const float (&ar)[P], const float (&ai)[P], float2* lds, int tid,
+                                                      int ja, int jb) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int j = bfly(i, tid, ja, jb);
+            const int jlo = j & (S - 1);
+            const int base = (j - jlo) * R + jlo;
+            if ((base >= M / 2) == (H == 1)) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    lds[lds_phys<R, S == 1>(base + r * S - H * (M / 2))] = make_float2(ar[i + r * NB], ai[i + r * NB]);
+            }
+        }
+    }
+    template <int H>
+    static __device__ __forceinline__ void read_half(float (&ar)[P], float (&ai)[P], const float2* lds, int tid, int ja,
+                                                     int jb) {
+        constexpr bool NEXT_PAIRED = !INV && (p + 1 == PL::NP - 1);
+        if constexpr (!NEXT_PAIRED) {
+#pragma unroll
+            for (int m = H * (P / 2); m < (H + 1) * (P / 2); ++m) {  // element tid + T*m >= M/2  <=>  m >= P/2
+                const float2 v = lds[lds_phys<R, S == 1>(tid + T * m - H * (M / 2))];
+                ar[m] = v.x;
+                ai[m] = v.y;
+            }
+        } else {
+            constexpr int Rn = PL::RL, NBn = P / Rn;
+#pragma unroll
+            for (int q = H * (Rn / 2); q < (H + 1) * (Rn / 2); ++q) {  // ja, jb < M/Rn: the top bit is q's
+                const float2 va = lds[lds_phys<R, S == 1>(ja + q * (M / Rn) - H * (M / 2))];
+                ar[NBn * q] = va.x;
+                ai[NBn * q] = va.y;
+                if constexpr (NBn == 2) {
+                    const float2 vb = lds[lds_phys<R, S == 1>(jb + q * (M / Rn) - H * (M / 2))];
+                    ar[2 * q + 1] = vb.x;
+                    ai[2 * q + 1] = vb.y;
+                }
+            }
+        }
+    }
+
     // gather what the NEXT pass needs.  Normally element tid + T*m -> register m; when the next
     // pass is the paired one, butterflies ja/jb: element j + q*(M/Rn) -> register i + 2q.
     static __device__ __forceinline__ void read(float (&ar)[P], float (&ai)[P], const float2* lds, int tid, int ja,
@@ -421,10 +471,21 @@ __device__ __forceinline__ void run_passes(float (&ar)[PL::P], float (&ai)[PL::P
         typename NX::Tw3 nx;
         if constexpr (NX::PREFETCHABLE) nx = NX::prefetch(tw, tid, ja, jb);
 #if !(ADSP_ABLATE & 4)
-        if constexpr (INV || p > 0) __syncthreads();  // everyone is done reading the previous exchange
-        PS::write(ar, ai, lds, tid, ja, jb);
-        __syncthreads();
-        PS::read(ar, ai, lds, tid, ja, jb);
+        if constexpr (PL::HALF) {
+            if constexpr (INV || p > 0) __syncthreads();  // everyone is done reading the previous exchange
+            PS::template write_half<0>(ar, ai, lds, tid, ja, jb);
+            __syncthreads();
+            PS::template read_half<0>(ar, ai, lds, tid, ja, jb);
+            __syncthreads();
+            PS::template write_half<1>(ar, ai, lds, tid, ja, jb);
+            __syncthreads();
+            PS::template read_half<1>(ar, ai, lds, tid, ja, jb);
+        } else {
+            if constexpr (INV || p > 0) __syncthreads();  // everyone is done reading the previous exchange
+            PS::write(ar, ai, lds, tid, ja, jb);
+            __syncthreads();
+            PS::read(ar, ai, lds, tid, ja, jb);
+        }
 #endif
         run_passes<PL, INV, p + 1>(ar, ai, lds, tw, tid, ja, jb, NX::PREFETCHABLE ? &nx : nullptr);
     }
@@ -1005,7 +1066,7 @@ __device__ __forceinline__ void transform_block(float (&xr)[PL::P], float (&xi)[
 // the kernel: one workgroup = CPB channels x one time block
 // ------------------------------------------------------------------------------------------
 template <class PL, int CPB, int FN, bool S16 = false, bool EPI = false>
-__global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(const KernelArgs a) {
+__global__ __launch_bounds__(PL::T* CPB, PL::MINW) void fftconv_kernel(const KernelArgs a) {
     constexpr int M = PL::M, P = PL::P, T = PL::T;
     constexpr int N = 2 * M / FN;  // chunk size
     constexpr int LOGN = __builtin_ctz(N);
@@ -1014,7 +1075,7 @@ __global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_kernel(con
 
     const int tid = static_cast<int>(threadIdx.x) % T;
     const int grp = static_cast<int>(threadIdx.x) / T;
-    lds += grp * M;
+    lds += grp * PL::LDS_ELEMS;
 
     // blockIdx -> (channel group, time block).  Blocks b % 8 land on XCD b % 8 (observed, speed
     // only): keep one channel group's consecutive time blocks on one XCD so the overlapping part
@@ -1139,13 +1200,13 @@ __device__ __forceinline__ void locate_chunk(int tau_biased, int N, float inv_n,
 }
 
 template <class PL, int CPB, bool S16 = false, bool EPI = false>
-__global__ __launch_bounds__(PL::T* CPB, ADSP_MIN_WAVES) void fftconv_generic_kernel(const KernelArgs a) {
+__global__ __launch_bounds__(PL::T* CPB, PL::MINW) void fftconv_generic_kernel(const KernelArgs a) {
     constexpr int M = PL::M, P = PL::P, T = PL::T;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2* lds = reinterpret_cast<float2*>(smem_raw);
     const int tid = static_cast<int>(threadIdx.x) % T;
     const int grp = static_cast<int>(threadIdx.x) / T;
-    lds += grp * M;
+    lds += grp * PL::LDS_ELEMS;
 
     const int lin = static_cast<int>(blockIdx.x);
     const int xcd = lin & 7;

@@ -27,7 +27,7 @@ constexpr int lds_bytes() {
 #if ADSP_ABLATE & 4096
     if (PL::M == 4096) return 44 * 1024;  // tuning: three workgroups per CU instead of four
 #endif
-    return PL::M * CPB * (int)sizeof(float2);
+    return PL::LDS_ELEMS * CPB * (int)sizeof(float2);
 }
 
 template <class PL, int CPB, int FN, bool S16, bool EPI>
