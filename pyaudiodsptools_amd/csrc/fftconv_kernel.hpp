@@ -472,14 +472,23 @@ __device__ __forceinline__ void run_passes(float (&ar)[PL::P], float (&ai)[PL::P
         if constexpr (NX::PREFETCHABLE) nx = NX::prefetch(tw, tid, ja, jb);
 #if !(ADSP_ABLATE & 4)
         if constexpr (PL::HALF) {
+            // round 0 lands in temporaries: the thread's own outputs for round 1 still sit in ar/ai (a butterfly writes
+            // in ONE round, so registers of both halves stay live until the second write); P/2 extra registers, between
+            // passes, where pressure is lowest
+            float tr[PL::P], ti[PL::P];
             if constexpr (INV || p > 0) __syncthreads();  // everyone is done reading the previous exchange
             PS::template write_half<0>(ar, ai, lds, tid, ja, jb);
             __syncthreads();
-            PS::template read_half<0>(ar, ai, lds, tid, ja, jb);
+            PS::template read_half<0>(tr, ti, lds, tid, ja, jb);
             __syncthreads();
             PS::template write_half<1>(ar, ai, lds, tid, ja, jb);
             __syncthreads();
             PS::template read_half<1>(ar, ai, lds, tid, ja, jb);
+#pragma unroll
+            for (int m = 0; m < PL::P / 2; ++m) {  // round 0 filled registers 0 .. P/2-1 (both read layouts)
+                ar[m] = tr[m];
+                ai[m] = ti[m];
+            }
         } else {
             if constexpr (INV || p > 0) __syncthreads();  // everyone is done reading the previous exchange
             PS::write(ar, ai, lds, tid, ja, jb);

@@ -19,6 +19,8 @@ const PlanInfo kVariants[] = {
     make_plan<Plan<8192, 64, 3, 8, 32, 32, 1, false, true, 2>, 1, 4, false, false>(),    // 9
     make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true, true, 5>, 1, 2, false, false>(),    // 10: headline plan, 16 KiB of LDS, 5 workgroups per CU
     make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true, true, 6>, 1, 2, false, false>(),    // 11: 6 workgroups per CU
+    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1, false, true, 4>, 1, 2, false, false>(),   // 12: M = 8192 at 4 workgroups per CU (128 VGPRs)
+    make_plan<Plan<16384, 32, 3, 32, 32, 16, 1, false, true, 3>, 1, 4, false, false>(),  // 13: M = 16384, 32 points per thread, 168 VGPRs (still one workgroup per CU: fewer registers alone)
 };
 }  // namespace
 
