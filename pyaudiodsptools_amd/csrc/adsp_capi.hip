@@ -174,6 +174,14 @@ void build_twiddles(const PlanInfo& pl, std::vector<float4>& tw) {
                         const float2 a = tw1(qs[h][0], jlo, R, S), b = tw1(qs[h][1], jlo, R, S);
                         tw.push_back(make_float4(a.x, a.y, b.x, b.y));
                     }
+            } else if (p > 0 && R == 32 && ADSP_TW2_RADIX32 && S >= ADSP_TW2_MIN_S) {
+                // two-level, radix 32: w^1..w^8, w^16, w^24 per jlo; the kernel forms w^(8a+b) = w^(8a) w^b
+                const int qs[5][2] = {{1, 2}, {3, 4}, {5, 6}, {7, 8}, {16, 24}};
+                for (int h = 0; h < 5; ++h)
+                    for (int jlo = 0; jlo < S; ++jlo) {
+                        const float2 a = tw1(qs[h][0], jlo, R, S), b = tw1(qs[h][1], jlo, R, S);
+                        tw.push_back(make_float4(a.x, a.y, b.x, b.y));
+                    }
             } else if (p > 0) {
                 for (int h = 0; h < R / 2; ++h)
                     for (int jlo = 0; jlo < S; ++jlo) {

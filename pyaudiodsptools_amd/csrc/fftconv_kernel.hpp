@@ -118,6 +118,9 @@ struct Plan {
     // Twiddles are stored as float4 (one 16-byte load costs the TA exactly what an 8-byte one does).
     //  radix 16: TWO-LEVEL, 3 float4 per j_lo = (w^1,w^2), (w^3,w^4), (w^8,w^12); the other nine powers
     //            w^(4a+b) = w^(4a) * w^b are formed in registers (36 flops instead of 72 bytes of table per butterfly)
+    //  radix 32: TWO-LEVEL, 5 float4 per j_lo = (w^1,w^2), (w^3,w^4), (w^5,w^6), (w^7,w^8), (w^16,w^24); the other 21
+    //            powers w^(8a+b) = w^(8a) * w^b in registers (5 instead of 16 table loads per butterfly: the large
+    //            transforms spend most of their vector-memory instructions on twiddles)
     //  other radices: (w_{2h+1}, w_{2h+2}), h < R/2.
 #ifndef ADSP_TW_PREFETCH
 #define ADSP_TW_PREFETCH 1
@@ -128,8 +131,13 @@ struct Plan {
 #ifndef ADSP_TW2_MIN_S
 #define ADSP_TW2_MIN_S 2
 #endif
-    static constexpr bool tw_two_level(int radix, int s) { return radix == 16 && s >= ADSP_TW2_MIN_S; }
-    static constexpr int tw_rows2(int radix, int s) { return tw_two_level(radix, s) ? 3 : radix / 2; }
+#ifndef ADSP_TW2_RADIX32
+#define ADSP_TW2_RADIX32 1
+#endif
+    static constexpr bool tw_two_level(int radix, int s) {
+        return (radix == 16 || (ADSP_TW2_RADIX32 && radix == 32)) && s >= ADSP_TW2_MIN_S;
+    }
+    static constexpr int tw_rows2(int radix, int s) { return tw_two_level(radix, s) ? (radix == 16 ? 3 : 5) : radix / 2; }
     static constexpr int tw_count(bool inverse) {
         int n = 0;
         for (int p = 1; p < NP_; ++p) n += tw_rows2(rad(inverse, p), stride(inverse, p)) * stride(inverse, p);
@@ -286,12 +294,16 @@ struct Pass {
 
     // two-level twiddle rows of a one-butterfly pass, loadable long before the pass runs (they depend on tid only)
     static constexpr bool PREFETCHABLE = ADSP_TW_PREFETCH && S > 1 && PL::tw_two_level(R, S) && NB == 1;
+    static constexpr int TWROWS = PL::tw_rows2(R, S);  // table rows of a two-level pass (3 for radix 16, 5 for radix 32)
     struct Tw3 {
-        float4 t0, t1, t2;
+        float4 t[5];
     };
     static __device__ __forceinline__ Tw3 prefetch(const float4* __restrict__ tw, int tid, int ja, int jb) {
         const int jlo = bfly(0, tid, ja, jb) & (S - 1);
-        return Tw3{tw[TWOFF + jlo], tw[TWOFF + S + jlo], tw[TWOFF + 2 * S + jlo]};
+        Tw3 r;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) r.t[k] = k < TWROWS ? tw[TWOFF + k * S + jlo] : make_float4(0.f, 0.f, 0.f, 0.f);
+        return r;
     }
 
     static __device__ __forceinline__ void compute(float (&ar)[P], float (&ai)[P], const float4* __restrict__ tw,
@@ -305,35 +317,48 @@ struct Pass {
                 ui[q] = ai[i + q * NB];
             }
             if constexpr (S > 1 && PL::tw_two_level(R, S)) {
-                // two-level twiddles: w^(4a+b) = w^(4a) * w^b
+                // two-level twiddles: w^(Ba+b) = w^(Ba) * w^b with B = 4 (radix 16) or 8 (radix 32)
                 const int jlo = bfly(i, tid, ja, jb) & (S - 1);
+                float4 t[5];
 #if ADSP_ABLATE & 1
-                const float4 t0 = tw[TWOFF + (jlo & 1)], t1 = tw[TWOFF + 2 + (jlo & 1)], t2 = tw[TWOFF + 4 + (jlo & 1)];
+#pragma unroll
+                for (int k = 0; k < TWROWS; ++k) t[k] = tw[TWOFF + 2 * k + (jlo & 1)];
 #else
-                float4 t0, t1, t2;
                 if constexpr (PREFETCHABLE) {
-                    t0 = pre->t0; t1 = pre->t1; t2 = pre->t2;
+#pragma unroll
+                    for (int k = 0; k < TWROWS; ++k) t[k] = pre->t[k];
                 } else {
-                    t0 = tw[TWOFF + jlo]; t1 = tw[TWOFF + S + jlo]; t2 = tw[TWOFF + 2 * S + jlo];
+#pragma unroll
+                    for (int k = 0; k < TWROWS; ++k) t[k] = tw[TWOFF + k * S + jlo];
                 }
 #endif
-                float wr[16], wi[16];
-                wr[1] = t0.x; wi[1] = t0.y; wr[2] = t0.z; wi[2] = t0.w;
-                wr[3] = t1.x; wi[3] = t1.y; wr[4] = t1.z; wi[4] = t1.w;
-                wr[8] = t2.x; wi[8] = t2.y; wr[12] = t2.z; wi[12] = t2.w;
-#pragma unroll
-                for (int a4 = 4; a4 < 16; a4 += 4) {
-#pragma unroll
-                    for (int b = 1; b < 4; ++b) {
-                        wr[a4 + b] = wr[a4] * wr[b] - wi[a4] * wi[b];
-                        wi[a4 + b] = wr[a4] * wi[b] + wi[a4] * wr[b];
-                    }
+                float wr[R], wi[R];
+                constexpr int B = R == 16 ? 4 : 8;
+                if constexpr (R == 16) {
+                    wr[1] = t[0].x; wi[1] = t[0].y; wr[2] = t[0].z; wi[2] = t[0].w;
+                    wr[3] = t[1].x; wi[3] = t[1].y; wr[4] = t[1].z; wi[4] = t[1].w;
+                    wr[8] = t[2].x; wi[8] = t[2].y; wr[12] = t[2].z; wi[12] = t[2].w;
+                } else {
+                    wr[1] = t[0].x; wi[1] = t[0].y; wr[2] = t[0].z; wi[2] = t[0].w;
+                    wr[3] = t[1].x; wi[3] = t[1].y; wr[4] = t[1].z; wi[4] = t[1].w;
+                    wr[5] = t[2].x; wi[5] = t[2].y; wr[6] = t[2].z; wi[6] = t[2].w;
+                    wr[7] = t[3].x; wi[7] = t[3].y; wr[8] = t[3].z; wi[8] = t[3].w;
+                    wr[16] = t[4].x; wi[16] = t[4].y; wr[24] = t[4].z; wi[24] = t[4].w;
                 }
-#pragma unroll
-                for (int q = 1; q < 16; ++q) {
+                // every power is used the moment it exists (forming all R of them first keeps 2R registers alive)
+                auto rot = [&](int q, float cr, float ci) {
                     const float xr = ur[q], xi = ui[q];
-                    ur[q] = xr * wr[q] - xi * wi[q];
-                    ui[q] = xr * wi[q] + xi * wr[q];
+                    ur[q] = xr * cr - xi * ci;
+                    ui[q] = xr * ci + xi * cr;
+                };
+#pragma unroll
+                for (int b = 1; b < B; ++b) rot(b, wr[b], wi[b]);
+#pragma unroll
+                for (int a4 = B; a4 < R; a4 += B) {
+                    rot(a4, wr[a4], wi[a4]);
+#pragma unroll
+                    for (int b = 1; b < B; ++b)
+                        rot(a4 + b, wr[a4] * wr[b] - wi[a4] * wi[b], wr[a4] * wi[b] + wi[a4] * wr[b]);
                 }
             } else if constexpr (S > 1) {
                 const int jlo = bfly(i, tid, ja, jb) & (S - 1);
@@ -367,6 +392,9 @@ struct Pass {
                 ar[i + r * NB] = vr[r];
                 ai[i + r * NB] = vi[r];
             }
+#ifdef ADSP_EXP_FENCE_BFLY
+            if constexpr (P >= 64 && NB > 1) __builtin_amdgcn_sched_barrier(0);
+#endif
         }
     }
 
@@ -580,6 +608,9 @@ __device__ __forceinline__ void spectrum_stage(float (&xr)[PL::P], float (&xi)[P
                     make_float2(f0.z, f0.w), make_float2(f1.x, f1.y));
             pair_op(xr[2 * r1], xi[2 * r1], xr[2 * (R - 1 - r1) + 1], xi[2 * (R - 1 - r1) + 1], make_float2(f1.z, f1.w),
                     make_float2(f2.x, f2.y), make_float2(f2.z, f2.w));
+#ifdef ADSP_EXP_FENCE_SPEC
+            if constexpr (R >= 32) { if (h % ADSP_EXP_FENCE_SPEC == ADSP_EXP_FENCE_SPEC - 1) __builtin_amdgcn_sched_barrier(0); }
+#endif
         }
     } else {
         // thread 0 owns the two self-paired butterflies j = 0 and j = T.
@@ -1210,7 +1241,7 @@ __device__ __forceinline__ void locate_chunk(int tau_biased, int N, float inv_n,
 
 template <class PL, int CPB, bool S16 = false, bool EPI = false>
 __global__ __launch_bounds__(PL::T* CPB, PL::MINW) void fftconv_generic_kernel(const KernelArgs a) {
-    constexpr int M = PL::M, P = PL::P, T = PL::T;
+    constexpr int P = PL::P, T = PL::T;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2* lds = reinterpret_cast<float2*>(smem_raw);
     const int tid = static_cast<int>(threadIdx.x) % T;

@@ -63,6 +63,16 @@ constexpr PlanInfo make_plan() {
 
 // M (complex points) x F/N -> plan.  Radices forward (inverse = reversed); last forward radix is P/2
 // (in-register pairing) or P (XL, cross-lane pairing) - see fftconv_kernel.hpp.
+// The two large transforms run their LDS exchanges over half a buffer (Plan::HALF) so that more than one or two
+// workgroups fit a CU - measured on MI355X (profiles/r2_shapes_session4.txt):
+//   M = 8192 : 32 points per thread, 168 VGPRs (3 waves per SIMD), 32 KiB of LDS -> THREE workgroups per CU  (+9 % over two)
+//   M = 16384: 64 points per thread, 4 waves per transform, 64 KiB of LDS        -> TWO workgroups per CU    (+13 % over one)
+#ifndef ADSP_PLAN_8192
+#define ADSP_PLAN_8192 Plan<8192, 32, 3, 32, 16, 16, 1, false, true, 3>
+#endif
+#ifndef ADSP_PLAN_16384
+#define ADSP_PLAN_16384 Plan<16384, 64, 3, 16, 32, 32, 1, false, true, 2>
+#endif
 #define ADSP_PLAN_LIST(S16, EPI)                                                    \
     make_plan<Plan<64, 16, 2, 8, 8, 1, 1>, 16, 2, S16, EPI>(),                        \
     make_plan<Plan<128, 16, 2, 16, 8, 1, 1>, 8, 2, S16, EPI>(),                       \
@@ -77,9 +87,9 @@ constexpr PlanInfo make_plan() {
     make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 4, S16, EPI>(),                     \
     make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 2, S16, EPI>(),              \
     make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 4, S16, EPI>(),              \
-    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1, 2, S16, EPI>(),                    \
-    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1, 4, S16, EPI>(),                    \
-    make_plan<Plan<16384, 32, 3, 32, 32, 16, 1>, 1, 4, S16, EPI>()
+    make_plan<ADSP_PLAN_8192, 1, 2, S16, EPI>(),                                      \
+    make_plan<ADSP_PLAN_8192, 1, 4, S16, EPI>(),                                      \
+    make_plan<ADSP_PLAN_16384, 1, 4, S16, EPI>()
 
 // tables live in plans_f32.hip / plans_s16.hip (internal linkage there: host-only data, the device pass only
 // needs to see the instantiations)
