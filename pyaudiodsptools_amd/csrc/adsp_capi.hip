@@ -286,46 +286,52 @@ int set_device(const adsp_engine* e) {
 int upload_pairs(adsp_engine* e, const float* H, hipStream_t stream, bool async = false) {
     const PlanInfo& pl = *e->plan;
     const int M = e->M, T = pl.T;
-    const int R = pl.XL ? pl.P : pl.P / 2;   // radix of the paired passes
+    const int R = pl.rad[pl.NP - 1];         // radix of the paired passes: P for XL plans, P/2, P/4 .. otherwise
     const int D = M / R;                     // bin spacing between a butterfly's outputs
-    const int npairs = pl.XL ? R / 2 : R;    // pair ops per regular thread
-    auto first_bin = [&](int t) {            // the butterfly whose outputs thread t pairs (k = bin + D*r)
-        if (!pl.XL) return t;
+    const int PU = pl.XL ? 1 : pl.P / R / 2; // pairs of butterflies per thread (in-register plans: (u*T + t, its mirror))
+    const int npairs = pl.XL ? R / 2 : R;    // pair ops per regular thread and pair of butterflies
+    auto first_bin = [&](int t, int u) {     // the butterfly whose outputs thread t pairs (k = bin + D*r)
+        if (!pl.XL) return u * T + t;
         const int lo = 32 * (t >> 6) + (t & 31);
         return (t & 32) ? (t == 32 ? T / 2 : T - lo) : lo;
     };
+    auto self_paired = [&](int t, int u) { return (t == 0 && u == 0) || (pl.XL && t == 32); };  // served by tab0
     // A real spectrum (zero-phase kernel) makes c1, c4 real and c2 imaginary: 3 floats per pair instead of 6.
     bool real_spec = true;
     for (int k = 0; k <= M && real_spec; ++k) real_spec = H[2 * k + 1] == 0.0f;
     if (getenv("ADSP_FORCE_COMPLEX")) real_spec = false;  // tuning: A/B the two spectrum stages on the same filter
     e->real_spec = real_spec;
-    // float4 layout [h][3][T]: (wc,g1) of pair 2h, (g2 of 2h, wc of 2h+1), (g1,g2) of 2h+1
-    std::vector<float4> tab((size_t)(npairs / 2) * 3 * T, make_float4(0.f, 0.f, 0.f, 0.f));
+    // float4 layout [u][h][3][T]: (wc,g1) of pair 2h, (g2 of 2h, wc of 2h+1), (g1,g2) of 2h+1
+    std::vector<float4> tab((size_t)PU * (npairs / 2) * 3 * T, make_float4(0.f, 0.f, 0.f, 0.f));
     if (real_spec) {
-        // [g][3][T] float4 = (c1.re, c4.re, c2.im) of pairs 4g .. 4g+3
+        // [u][g][3][T] float4 = (c1.re, c4.re, c2.im) of pairs 4g .. 4g+3
         std::vector<float> flat(12);
-        for (int g = 0; g < npairs / 4; ++g)
-            for (int tid = 0; tid < T; ++tid) {
-                if (tid == 0 || (pl.XL && tid == 32)) continue;
-                for (int q = 0; q < 4; ++q) {
-                    const PairEntry pe = pair_entry(H, M, first_bin(tid) + D * (4 * g + q));
-                    flat[3 * q + 0] = pe.wc.x;
-                    flat[3 * q + 1] = pe.g2.x;
-                    flat[3 * q + 2] = pe.g1.y;
+        for (int u = 0; u < PU; ++u)
+            for (int g = 0; g < npairs / 4; ++g)
+                for (int tid = 0; tid < T; ++tid) {
+                    if (self_paired(tid, u)) continue;
+                    for (int q = 0; q < 4; ++q) {
+                        const PairEntry pe = pair_entry(H, M, first_bin(tid, u) + D * (4 * g + q));
+                        flat[3 * q + 0] = pe.wc.x;
+                        flat[3 * q + 1] = pe.g2.x;
+                        flat[3 * q + 2] = pe.g1.y;
+                    }
+                    for (int j = 0; j < 3; ++j)
+                        tab[((size_t)(u * (npairs / 4) + g) * 3 + j) * T + tid] =
+                            make_float4(flat[4 * j], flat[4 * j + 1], flat[4 * j + 2], flat[4 * j + 3]);
                 }
-                for (int j = 0; j < 3; ++j)
-                    tab[(size_t)(g * 3 + j) * T + tid] = make_float4(flat[4 * j], flat[4 * j + 1], flat[4 * j + 2], flat[4 * j + 3]);
-            }
     }
-    for (int h = 0; h < npairs / 2 && !real_spec; ++h)
-        for (int tid = 0; tid < T; ++tid) {
-            if (tid == 0 || (pl.XL && tid == 32)) continue;  // self-paired butterflies: tab0
-            const PairEntry a = pair_entry(H, M, first_bin(tid) + D * (2 * h));
-            const PairEntry b = pair_entry(H, M, first_bin(tid) + D * (2 * h + 1));
-            tab[(size_t)(h * 3 + 0) * T + tid] = make_float4(a.wc.x, a.wc.y, a.g1.x, a.g1.y);
-            tab[(size_t)(h * 3 + 1) * T + tid] = make_float4(a.g2.x, a.g2.y, b.wc.x, b.wc.y);
-            tab[(size_t)(h * 3 + 2) * T + tid] = make_float4(b.g1.x, b.g1.y, b.g2.x, b.g2.y);
-        }
+    for (int u = 0; u < PU && !real_spec; ++u)
+        for (int h = 0; h < npairs / 2; ++h)
+            for (int tid = 0; tid < T; ++tid) {
+                if (self_paired(tid, u)) continue;  // self-paired butterflies: tab0
+                const PairEntry a = pair_entry(H, M, first_bin(tid, u) + D * (2 * h));
+                const PairEntry b = pair_entry(H, M, first_bin(tid, u) + D * (2 * h + 1));
+                const size_t row = (size_t)(u * (npairs / 2) + h) * 3;
+                tab[(row + 0) * T + tid] = make_float4(a.wc.x, a.wc.y, a.g1.x, a.g1.y);
+                tab[(row + 1) * T + tid] = make_float4(a.g2.x, a.g2.y, b.wc.x, b.wc.y);
+                tab[(row + 2) * T + tid] = make_float4(b.g1.x, b.g1.y, b.g2.x, b.g2.y);
+            }
     std::vector<float2> tab0((size_t)(R + 1) * 3);
     auto put0 = [&](int idx, int k) {
         const PairEntry pe = pair_entry(H, M, k);
@@ -577,8 +583,8 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     if ((err = hipMalloc(&e->tw, tw_bytes)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
     if (!tw.empty() && (err = hipMemcpy(e->tw, tw.data(), tw.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess)
         return bail(fail(ADSP_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(err)));
-    const int R = pl->XL ? pl->P : pl->P / 2;
-    if ((err = hipMalloc(&e->pair, (size_t)R * 3 * pl->T * sizeof(float4))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
+    const int R = pl->rad[pl->NP - 1];  // radix of the paired passes
+    if ((err = hipMalloc(&e->pair, (size_t)(pl->P / 2) * 3 * pl->T * sizeof(float4))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
     if ((err = hipMalloc(&e->pair0, (size_t)(R + 1) * 3 * sizeof(float2))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
     if ((err = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(err)));
     if ((err = hipEventCreateWithFlags(&e->ev_in_ready, hipEventDisableTiming)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(err)));

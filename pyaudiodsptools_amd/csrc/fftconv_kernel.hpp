@@ -149,8 +149,17 @@ struct Plan {
         return n;
     }
     static constexpr int tw_total = tw_count(false) + tw_count(true);
-    static constexpr int RL = XL_ ? P_ : P_ / 2;  // radix of the paired passes
-    static_assert(fwd(NP_ - 1) == RL, "last forward radix must be P/2 (two butterflies per thread), or P for XL plans");
+    static constexpr int RL = fwd(NP_ - 1);  // radix of the paired passes (last forward = first inverse)
+    static constexpr int NBL = P_ / RL;      // butterflies per thread there: 1 (XL, partner in lane ^ 32) or an even number -
+                                             // NBL/2 pairs (j, M/RL - j) whose real-FFT partners meet in registers
+    static_assert(XL_ ? NBL == 1 : (NBL >= 2 && NBL % 2 == 0), "last forward radix: P for XL plans, P/2, P/4, .. otherwise");
+    // butterfly i of the paired pass of thread tid (in-register plans).  Pair u = i/2: a-side u*T + tid, b-side its mirror
+    // NBL*T - (u*T + tid); thread 0's pair 0 holds the two self-paired butterflies 0 and NBL*T/2.
+    static __device__ __forceinline__ int paired_bfly(int i, int tid) {
+        const int u = i >> 1;
+        if ((i & 1) == 0) return u * T + tid;
+        return (u == 0 && tid == 0) ? NBL * T / 2 : (NBL - u) * T - tid;
+    }
     static_assert(!XL_ || (M_ / P_) % 64 == 0, "XL plans need whole waves");
     static_assert(stride(false, NP_) == M_, "radices must multiply to M");
     static_assert(!HALF_ || M_ >= 2048, "half-buffer exchanges: the swizzle must stay below bit log2(M) - 1");
@@ -285,10 +294,14 @@ struct Pass {
     static constexpr bool PAIRED = INV ? (p == 0) : (p == PL::NP - 1);
     static constexpr bool LAST = (p == PL::NP - 1);
     static constexpr int TWOFF = PL::tw_offset(INV, p);
-    static_assert(!PAIRED || NB == (PL::XL ? 1 : 2), "paired pass: two butterflies per thread (one for XL plans)");
+    static_assert(!PAIRED || NB == PL::NBL, "paired pass: NBL butterflies per thread");
 
     static __device__ __forceinline__ int bfly(int i, int tid, int ja, int jb) {
-        if constexpr (PAIRED) return i == 0 ? ja : jb;
+        if constexpr (PAIRED) {
+            if constexpr (PL::XL) return ja;
+            if constexpr (PL::NBL == 2) return i == 0 ? ja : jb;  // (= paired_bfly, already in registers)
+            return PL::paired_bfly(i, tid);
+        }
         return tid + T * i;
     }
 
@@ -392,9 +405,6 @@ struct Pass {
                 ar[i + r * NB] = vr[r];
                 ai[i + r * NB] = vi[r];
             }
-#ifdef ADSP_EXP_FENCE_BFLY
-            if constexpr (P >= 64 && NB > 1) __builtin_amdgcn_sched_barrier(0);
-#endif
         }
     }
 
@@ -443,15 +453,14 @@ struct Pass {
             }
         } else {
             constexpr int Rn = PL::RL, NBn = P / Rn;
+            using NXT = Pass<PL, INV, p + 1>;
 #pragma unroll
-            for (int q = H * (Rn / 2); q < (H + 1) * (Rn / 2); ++q) {  // ja, jb < M/Rn: the top bit is q's
-                const float2 va = lds[lds_phys<R, S == 1>(ja + q * (M / Rn) - H * (M / 2))];
-                ar[NBn * q] = va.x;
-                ai[NBn * q] = va.y;
-                if constexpr (NBn == 2) {
-                    const float2 vb = lds[lds_phys<R, S == 1>(jb + q * (M / Rn) - H * (M / 2))];
-                    ar[2 * q + 1] = vb.x;
-                    ai[2 * q + 1] = vb.y;
+            for (int q = H * (Rn / 2); q < (H + 1) * (Rn / 2); ++q) {  // butterfly indices < M/Rn: the top bit is q's
+#pragma unroll
+                for (int i = 0; i < NBn; ++i) {
+                    const float2 v = lds[lds_phys<R, S == 1>(NXT::bfly(i, tid, ja, jb) + q * (M / Rn) - H * (M / 2))];
+                    ar[NBn * q + i] = v.x;
+                    ai[NBn * q + i] = v.y;
                 }
             }
         }
@@ -471,15 +480,14 @@ struct Pass {
             }
         } else {
             constexpr int Rn = PL::RL, NBn = P / Rn;
+            using NXT = Pass<PL, INV, p + 1>;
 #pragma unroll
             for (int q = 0; q < Rn; ++q) {
-                const float2 va = lds[lds_phys<R, S == 1>(ja + q * (M / Rn))];
-                ar[NBn * q] = va.x;
-                ai[NBn * q] = va.y;
-                if constexpr (NBn == 2) {
-                    const float2 vb = lds[lds_phys<R, S == 1>(jb + q * (M / Rn))];
-                    ar[2 * q + 1] = vb.x;
-                    ai[2 * q + 1] = vb.y;
+#pragma unroll
+                for (int i = 0; i < NBn; ++i) {
+                    const float2 v = lds[lds_phys<R, S == 1>(NXT::bfly(i, tid, ja, jb) + q * (M / Rn))];
+                    ar[NBn * q + i] = v.x;
+                    ai[NBn * q + i] = v.y;
                 }
             }
         }
@@ -577,64 +585,70 @@ template <class PL>
 __device__ __forceinline__ void spectrum_stage(float (&xr)[PL::P], float (&xi)[PL::P],
                                                const float4* __restrict__ pair, const float2* __restrict__ pair0,
                                                int tid, bool real_spec) {
-    constexpr int R = PL::RL, T = PL::T;
+    constexpr int R = PL::RL, T = PL::T, NB = PL::NBL;
     static_assert(R % 4 == 0, "real-spectrum table packs four pairs per group");
-    // registers: butterfly a (j = ja) output r -> [2r];  butterfly b (j = jb) output r -> [2r+1]
-    if (tid != 0 && real_spec) {  // wave-uniform flag
+    // registers: pair u of butterflies (a: j = u*T + tid, b: its mirror): a's output r -> [NB*r + 2u], b's -> [NB*r + 2u + 1];
+    // bin k = j + (M/R)*r of a meets M - k = output R-1-r of b.  Tables: [u][...][T], the layouts of the NB = 2 case per pair.
 #pragma unroll
-        for (int g = 0; g < R / 4; ++g) {
-            float c[12];
-            load_real_group(pair, g, T, tid, c);
+    for (int u = 0; u < NB / 2; ++u) {
+        const bool self_paired = u == 0 && tid == 0;  // thread 0's pair 0: butterflies 0 and M/R/2 pair within themselves
+        if (!self_paired && real_spec) {  // wave-uniform flag
+            const float4* tab = pair + u * (R / 4) * 3 * T;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = 4 * g + q;
-                pair_op_real(xr[2 * r], xi[2 * r], xr[2 * (R - 1 - r) + 1], xi[2 * (R - 1 - r) + 1], c[3 * q], c[3 * q + 1],
-                             c[3 * q + 2]);
+            for (int g = 0; g < R / 4; ++g) {
+                float c[12];
+                load_real_group(tab, g, T, tid, c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = 4 * g + q;
+                    pair_op_real(xr[NB * r + 2 * u], xi[NB * r + 2 * u], xr[NB * (R - 1 - r) + 2 * u + 1],
+                                 xi[NB * (R - 1 - r) + 2 * u + 1], c[3 * q], c[3 * q + 1], c[3 * q + 2]);
+                }
             }
-        }
-    } else if (tid != 0) {
-        // k = tid + 2T*r pairs with M-k = jb + 2T*(R-1-r); two pairs share three 16-byte table loads
+        } else if (!self_paired) {
+            // two bin pairs share three 16-byte table loads
+            const float4* tab = pair + u * (R / 2) * 3 * T;
 #pragma unroll
-        for (int h = 0; h < R / 2; ++h) {
+            for (int h = 0; h < R / 2; ++h) {
 #if ADSP_ABLATE & 2
-            const float4 f0 = pair[(tid & 1)], f1 = pair[T + (tid & 1)], f2 = pair[2 * T + (tid & 1)];
+                const float4 f0 = tab[(tid & 1)], f1 = tab[T + (tid & 1)], f2 = tab[2 * T + (tid & 1)];
 #else
-            const float4 f0 = pair[(h * 3 + 0) * T + tid];
-            const float4 f1 = pair[(h * 3 + 1) * T + tid];
-            const float4 f2 = pair[(h * 3 + 2) * T + tid];
+                const float4 f0 = tab[(h * 3 + 0) * T + tid];
+                const float4 f1 = tab[(h * 3 + 1) * T + tid];
+                const float4 f2 = tab[(h * 3 + 2) * T + tid];
 #endif
-            const int r0 = 2 * h, r1 = 2 * h + 1;
-            pair_op(xr[2 * r0], xi[2 * r0], xr[2 * (R - 1 - r0) + 1], xi[2 * (R - 1 - r0) + 1], make_float2(f0.x, f0.y),
-                    make_float2(f0.z, f0.w), make_float2(f1.x, f1.y));
-            pair_op(xr[2 * r1], xi[2 * r1], xr[2 * (R - 1 - r1) + 1], xi[2 * (R - 1 - r1) + 1], make_float2(f1.z, f1.w),
-                    make_float2(f2.x, f2.y), make_float2(f2.z, f2.w));
-#ifdef ADSP_EXP_FENCE_SPEC
-            if constexpr (R >= 32) { if (h % ADSP_EXP_FENCE_SPEC == ADSP_EXP_FENCE_SPEC - 1) __builtin_amdgcn_sched_barrier(0); }
-#endif
-        }
-    } else {
-        // thread 0 owns the two self-paired butterflies j = 0 and j = T.
-        // entry 0: k = 0 (DC + Nyquist), entry 1: k = M/2, entries 2..: a-pairs r = 1..R/2-1
-        // (k = 2T r with 2T (R-r)), then b-pairs r = 0..R/2-1 (k = T + 2T r with T + 2T (R-1-r)).
-        {
-            float tr = xr[0], ti = xi[0];
-            pair_op(xr[0], xi[0], tr, ti, pair0[0], pair0[1], pair0[2]);
-        }
-        {
-            float tr = xr[R], ti = xi[R];  // register 2*(R/2)
-            pair_op(xr[R], xi[R], tr, ti, pair0[3], pair0[4], pair0[5]);
-        }
+                const int r0 = 2 * h, r1 = 2 * h + 1;
+                pair_op(xr[NB * r0 + 2 * u], xi[NB * r0 + 2 * u], xr[NB * (R - 1 - r0) + 2 * u + 1],
+                        xi[NB * (R - 1 - r0) + 2 * u + 1], make_float2(f0.x, f0.y), make_float2(f0.z, f0.w),
+                        make_float2(f1.x, f1.y));
+                pair_op(xr[NB * r1 + 2 * u], xi[NB * r1 + 2 * u], xr[NB * (R - 1 - r1) + 2 * u + 1],
+                        xi[NB * (R - 1 - r1) + 2 * u + 1], make_float2(f1.z, f1.w), make_float2(f2.x, f2.y),
+                        make_float2(f2.z, f2.w));
+            }
+        } else {
+            // thread 0, pair 0 (u == 0 here): the self-paired butterflies j = 0 (registers NB*r) and j = M/R/2 (NB*r + 1).
+            // entry 0: k = 0 (DC + Nyquist), entry 1: k = M/2, entries 2..: a-pairs r = 1..R/2-1
+            // (k = D r with D (R-r), D = M/R), then b-pairs r = 0..R/2-1 (k = D/2 + D r with D/2 + D (R-1-r)).
+            {
+                float tr = xr[0], ti = xi[0];
+                pair_op(xr[0], xi[0], tr, ti, pair0[0], pair0[1], pair0[2]);
+            }
+            {
+                float tr = xr[NB * (R / 2)], ti = xi[NB * (R / 2)];
+                pair_op(xr[NB * (R / 2)], xi[NB * (R / 2)], tr, ti, pair0[3], pair0[4], pair0[5]);
+            }
 #pragma unroll
-        for (int r = 1; r < R / 2; ++r) {
-            const int e = 2 + (r - 1);
-            pair_op(xr[2 * r], xi[2 * r], xr[2 * (R - r)], xi[2 * (R - r)], pair0[e * 3], pair0[e * 3 + 1],
-                    pair0[e * 3 + 2]);
-        }
+            for (int r = 1; r < R / 2; ++r) {
+                const int e = 2 + (r - 1);
+                pair_op(xr[NB * r], xi[NB * r], xr[NB * (R - r)], xi[NB * (R - r)], pair0[e * 3], pair0[e * 3 + 1],
+                        pair0[e * 3 + 2]);
+            }
 #pragma unroll
-        for (int r = 0; r < R / 2; ++r) {
-            const int e = 2 + (R / 2 - 1) + r;
-            pair_op(xr[2 * r + 1], xi[2 * r + 1], xr[2 * (R - 1 - r) + 1], xi[2 * (R - 1 - r) + 1], pair0[e * 3],
-                    pair0[e * 3 + 1], pair0[e * 3 + 2]);
+            for (int r = 0; r < R / 2; ++r) {
+                const int e = 2 + (R / 2 - 1) + r;
+                pair_op(xr[NB * r + 1], xi[NB * r + 1], xr[NB * (R - 1 - r) + 1], xi[NB * (R - 1 - r) + 1], pair0[e * 3],
+                        pair0[e * 3 + 1], pair0[e * 3 + 2]);
+            }
         }
     }
 }
@@ -1088,8 +1102,8 @@ __device__ __forceinline__ void transform_block(float (&xr)[PL::P], float (&xi)[
         ja = (tid & 32) ? (tid == 32 ? T / 2 : T - lo) : lo;
         jb = 0;
     } else {
-        ja = tid;
-        jb = (tid == 0) ? T : 2 * T - tid;
+        ja = tid;                                                     // = paired_bfly(0, tid)
+        jb = (tid == 0) ? PL::NBL * T / 2 : PL::NBL * T - tid;        // = paired_bfly(1, tid)
     }
 
     run_passes<PL, false, 0>(xr, xi, lds, a.tw, tid, ja, jb);

@@ -18,6 +18,9 @@ const PlanInfo kVariants[] = {
     make_plan<Plan<8192, 64, 3, 8, 32, 32, 1, false, true, 2>, 1, 2, false, false>(),   // 9: 64 points per thread, 2 waves per transform (-3 % against 5)
     make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true, true, 5>, 1, 2, false, false>(),   // 10: headline plan, 16 KiB of LDS, FIVE workgroups per CU at 96 VGPRs (-9 %)
     make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true, true, 6>, 1, 2, false, false>(),   // 11: six at 80 VGPRs (-20 %)
+    make_plan<Plan<16384, 64, 3, 32, 32, 16, 1, false, true, 2>, 1, 4, false, false>(),  // 12: 64 points per thread, paired passes of radix 16 (4 butterflies = 2 pairs per thread)
+    make_plan<Plan<16384, 64, 3, 16, 32, 32, 1, false, true, 2>, 1, 4, false, false>(),  // 13: paired passes of radix 32 (120 bytes of scratch per lane)
+    make_plan<Plan<8192, 32, 3, 16, 32, 16, 1, false, true, 3>, 1, 2, false, false>(),   // 14: M = 8192 with paired passes of radix 16
 };
 }  // namespace
 
