@@ -329,24 +329,32 @@ def main():
     eng_desc = {"fft_size": main_run.eng.geometry.fft_size, "real": main_run.eng.real_spectrum,
                 "kept": N if args.mode == "stream" else main_run.eng.block_outputs, "taps": len(fir.taps)}
 
+    # The figures below are additions to the line: none of them may cost the driver its one JSON line, so each is
+    # fenced - a failure is reported in place of the figure.
     extra_stream = latency = None
     if world == 1 and args.mode != "stream" and not args.no_stream_extra:
-        del main_run.ins, main_run.outs
-        torch.cuda.empty_cache()
-        extra_stream = stream_figures(args, fir, dev, local_rank, world, rank, alg_bytes)
-    if world == 1 and not args.no_latency and args.io == "f32" and args.effect == "none":
-        # SURVEY 8d "also report": config 3 in its real-time call pattern and the numpy-API call
-        if args.mode != "stream" and hasattr(main_run, "ins"):
+        try:
             del main_run.ins, main_run.outs
             torch.cuda.empty_cache()
-        a3 = parse(["--filter", "eq3", "--chunk", "512", "--fs", "44100", "--channels", "4096"] + (["--no-graph"] if args.no_graph else []))
-        a3.prewarm_ms = min(args.prewarm_ms, 100.0)
-        s3 = stream_figures(a3, make_fir(a3), dev, local_rank, world, rank, ALG_BYTES_PER_SAMPLE, steps=4096)
-        latency = {"config3_eq3_2048_stereo_pairs_x_512": {k: s3[k] for k in ("us_per_step", "avg_kernel_us", "value", "roofline_frac", "graph") if k in s3},
-                   "numpy_api_apply_us_per_call": round(numpy_api_latency(), 2),
-                   "note": "config 3 = CreateEQ3BandFFT(100,2,700,-4,8000,5) on 4096 mono channels (2048 stereo pairs) x 512 samples, one launch "
-                           "per step (zero-copy ring); numpy API = CreateLowCutFilter(800).apply(float32[4096]) -> float32[4096], 1 channel, host "
-                           "buffers (PCIe + launch bound, never `value`)"}
+            extra_stream = stream_figures(args, fir, dev, local_rank, world, rank, alg_bytes)
+        except Exception as exc:
+            extra_stream = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    if world == 1 and not args.no_latency and args.io == "f32" and args.effect == "none":
+        # SURVEY 8d "also report": config 3 in its real-time call pattern and the numpy-API call
+        try:
+            if args.mode != "stream" and hasattr(main_run, "ins"):
+                del main_run.ins, main_run.outs
+                torch.cuda.empty_cache()
+            a3 = parse(["--filter", "eq3", "--chunk", "512", "--fs", "44100", "--channels", "4096"] + (["--no-graph"] if args.no_graph else []))
+            a3.prewarm_ms = min(args.prewarm_ms, 100.0)
+            s3 = stream_figures(a3, make_fir(a3), dev, local_rank, world, rank, ALG_BYTES_PER_SAMPLE, steps=4096)
+            latency = {"config3_eq3_2048_stereo_pairs_x_512": {k: s3[k] for k in ("us_per_step", "avg_kernel_us", "value", "roofline_frac", "graph") if k in s3},
+                       "numpy_api_apply_us_per_call": round(numpy_api_latency(), 2),
+                       "note": "config 3 = CreateEQ3BandFFT(100,2,700,-4,8000,5) on 4096 mono channels (2048 stereo pairs) x 512 samples, one launch "
+                               "per step (zero-copy ring); numpy API = CreateLowCutFilter(800).apply(float32[4096]) -> float32[4096], 1 channel, host "
+                               "buffers (PCIe + launch bound, never `value`)"}
+        except Exception as exc:
+            latency = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
     if rank == 0:
         value = sps * world * steps / wall / 1e6
@@ -398,7 +406,16 @@ def main():
         if latency:
             line["latency"] = latency
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args)
+            try:
+                line["cpu_baseline"] = cpu_baseline(args)
+            except Exception as exc:  # e.g. no process pool in this container: the one-process figure still stands
+                try:
+                    from oracle import cpu_bench
+                    smp, el = cpu_bench.run_worker((args.filter, "literal3n", args.chunk, args.fs, 1, args.cpu_seconds, 1234))
+                    line["cpu_baseline"] = {"value": round(smp / el / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                                            "sample": f"oracle literal 3N complex fft/ifft, ONE process ({type(exc).__name__} from the process pool: {exc})"[:400]}
+                except Exception as exc2:
+                    line["cpu_baseline"] = {"error": f"{type(exc2).__name__}: {exc2}"[:300]}
         sys.stdout.flush()
         try:  # RCCL prints a version banner through C stdio: push it out BEFORE the one JSON line, not after it at exit
             import ctypes
