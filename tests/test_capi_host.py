@@ -31,7 +31,8 @@ def test_plans_cover_supported_chunk_sizes():
             d = _capi.plan_describe(n, f)
             assert d["complex_points"] == f // 2
             assert d["threads_per_transform"] * d["points_per_thread"] == f // 2
-            assert d["lds_bytes"] == d["channels_per_workgroup"] * (f // 2) * 8 <= 160 * 1024
+            full = d["channels_per_workgroup"] * (f // 2) * 8  # one complex64 per point; the large transforms exchange through half a buffer
+            assert d["lds_bytes"] == (full // 2 if f // 2 >= 8192 else full) <= 64 * 1024
             assert (n // 4) % (2 * d["threads_per_transform"]) == 0  # design.py's N/4 granularity is legal
     assert lib.adsp_plan_supported(3000, 6000) != 0   # transforms are powers of two
     assert lib.adsp_plan_supported(32, 64) != 0       # ... of at least 128 points
@@ -95,6 +96,77 @@ def test_host_overlap_save_math_against_golden(golden):
                 y = np.fft.irfft(np.fft.rfft(padded[a:a + geo.fft_size]) * spec, geo.fft_size)
                 out[o:o + v] = y[geo.out_offset:geo.out_offset + v]
             assert_parity(out[:chunks * n], golden["kat_streams"][name], what=f"{name} V={v}")
+
+
+def test_trimmed_chain_on_the_host_side_of_the_abi(golden):
+    """The fused LowCut -> EQ3 -> HighCut chain with its negligible end taps left out (FirStream.trimmed): geometry,
+    error bound, and - with numpy's rfft in place of the kernel, window tail zeroed like the kernel's window skip - golden E."""
+    from pyaudiodsptools_amd import design
+    from conftest import assert_parity, seeded_stream
+    n, fs = 8192, 96000
+    lc = design.FirStream(design.lowcut_kernel(800, fs, n), n)
+    eq = design.FirStream(design.eq3_composite(100, 2, 700, -4, 8000, 5, fs, n), n)
+    hc = design.FirStream(design.highcut_kernel(8000, fs, n), n)
+    full = lc.then(eq).then(hc)
+    fir = full.trimmed()
+    dropped_front = full.lookahead - fir.lookahead
+    assert len(full.taps) == 16377 and len(fir.taps) == 9401 and fir.delay == full.delay + dropped_front
+    kept = np.zeros(len(full.taps), bool)
+    kept[dropped_front:dropped_front + len(fir.taps)] = True
+    assert np.array_equal(full.taps[kept], fir.taps)
+    assert np.abs(full.taps[~kept]).sum() <= design.TRIM_EPS * np.abs(full.taps).sum()  # the worst-case output change
+    assert full.trimmed(0.0) is full and lc.trimmed() is not None
+    geo, geo_full = design.overlap_save_geometry(fir, 0, "batch"), design.overlap_save_geometry(full, 0, "batch")
+    assert (geo.fft_size, geo.history_chunks, geo.max_block_outputs) == (4 * n, 4, 11 * n // 4)
+    assert (geo_full.fft_size, geo_full.history_chunks, geo_full.max_block_outputs) == (4 * n, 5, 2 * n)
+    spec = design.engine_spectrum(fir, geo).view(np.complex64).astype(np.complex128)
+    chunks = 12
+    x = seeded_stream(4321, chunks * n).astype(np.float64)
+    padded = np.concatenate([np.zeros(geo.history_chunks * n), x, np.zeros(geo.fft_size)])
+    for v in (n, geo.max_block_outputs):
+        reach = max(0, -geo.shift)
+        out = np.zeros(chunks * n + v)
+        for o in range(0, chunks * n, v):
+            a = o - geo.lookback + geo.history_chunks * n
+            win = padded[a:a + geo.fft_size].copy()
+            win[geo.out_offset + v + reach:] = 0.0  # what adsp_set_kernel_reach lets the kernel leave unfetched
+            y = np.fft.irfft(np.fft.rfft(win) * spec, geo.fft_size)
+            out[o:o + v] = y[geo.out_offset:geo.out_offset + v]
+        assert_parity(out[:chunks * n], golden["kat_chain"]["E"], what=f"trimmed chain V={v}")
+
+
+def test_window_tail_skip_is_exact_for_zero_phase_filters(golden):
+    """adsp_set_kernel_reach on the host side: for a zero-phase cut filter a single-step block (V = N) only depends on the
+    first out_offset + N + (L-1)/2 = 1.5 N - 1 window positions - zeroing the rest changes nothing."""
+    from pyaudiodsptools_amd import design
+    n = 512
+    fir = design.FirStream(design.lowcut_kernel(200, 44100, n), n)
+    geo = design.overlap_save_geometry(fir)
+    assert geo.zero_phase and geo.shift == -(len(fir.taps) - 1) // 2
+    spec = design.engine_spectrum(fir, geo).view(np.complex64).astype(np.complex128)
+    win = np.random.default_rng(3).uniform(-1, 1, geo.fft_size)
+    need = geo.out_offset + n - geo.shift
+    assert need == 3 * n // 2 - 1
+    cut = win.copy()
+    cut[need:] = 0.0
+    full = np.fft.irfft(np.fft.rfft(win) * spec, geo.fft_size)[geo.out_offset:geo.out_offset + n]
+    part = np.fft.irfft(np.fft.rfft(cut) * spec, geo.fft_size)[geo.out_offset:geo.out_offset + n]
+    # (exactly nothing in exact arithmetic; the float32 rounding of the spectrum spreads 1e-8 of the kernel over all F taps)
+    assert np.abs(full - part).max() <= 1e-7
+    cut[need - 96:] = 0.0  # noticeably fewer positions are NOT enough (the outermost taps of a Blackman window are ~0)
+    less = np.fft.irfft(np.fft.rfft(cut) * spec, geo.fft_size)[geo.out_offset:geo.out_offset + n]
+    assert np.abs(full - less).max() > 1e-5
+
+
+def test_cpu_baseline_helpers():
+    """bench.py's cpu_baseline leg (oracle/cpu_bench.py): worker returns samples and seconds, core detection is sane."""
+    from oracle import cpu_bench
+    assert 1 <= cpu_bench.physical_cores() <= (os.cpu_count() or 1)
+    samples, el = cpu_bench.run_worker(("lowcut", "literal3n", 512, 44100, 1, 0.05, 1))
+    assert samples > 0 and el >= 0.05
+    samples, el = cpu_bench.run_worker(("eq3", "rfft2n", 512, 44100, 4, 0.05, 1))
+    assert samples > 0 and samples % (4 * 512) == 0
+    assert cpu_bench.run_worker(("chain", "rfft2n", 512, 44100, 4, 0.05, 1)) == (0, 0.0)  # does not fit a 2N transform
 
 
 def test_no_gpu_means_loud_failure():
