@@ -21,6 +21,11 @@ const PlanInfo kVariants[] = {
     make_plan<Plan<16384, 64, 3, 32, 32, 16, 1, false, true, 2>, 1, 4, false, false>(),  // 12: 64 points per thread, paired passes of radix 16 (4 butterflies = 2 pairs per thread)
     make_plan<Plan<16384, 64, 3, 16, 32, 32, 1, false, true, 2>, 1, 4, false, false>(),  // 13: paired passes of radix 32 (120 bytes of scratch per lane)
     make_plan<Plan<8192, 32, 3, 16, 32, 16, 1, false, true, 3>, 1, 2, false, false>(),   // 14: M = 8192 with paired passes of radix 16
+    make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 4, 2, false, false>(),                      // 15: M = 512 (config 3's stream transform), 4 channels per workgroup
+    make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 8, 2, false, false>(),                      // 16: 8 channels per workgroup
+    make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 1, 2, false, false>(),                      // 17: 1 channel (half a wave) per workgroup
+    make_plan<Plan<512, 32, 2, 32, 16, 1, 1>, 4, 2, false, false>(),                     // 18: TWO passes (32 points per thread, 16 threads per transform), 4 channels per wave
+    make_plan<Plan<512, 32, 2, 32, 16, 1, 1>, 8, 2, false, false>(),                     // 19: same, 8 channels per workgroup
 };
 }  // namespace
 
