@@ -201,6 +201,10 @@ ADSP_API int adsp_apply_ring(adsp_engine* engine, void* d_out, void* stream);
 /* Test hooks: the engine's history as [history_chunks][C][N] host floats, oldest first
  * (the reference's float32_array_input_3/_2). */
 ADSP_API int adsp_get_state(adsp_engine* engine, void* host_history);
+/* The state a fused effect adds to a checkpoint: for the tremolo the position of its LFO (the length of the reference's
+ * table buffer, EffectTremolo.py:40-45); 0 for every stateless effect.  adsp_reset restarts the LFO as well. */
+ADSP_API int adsp_get_epilogue_state(const adsp_engine* engine, long long* state);
+ADSP_API int adsp_set_epilogue_state(adsp_engine* engine, long long state);
 ADSP_API int adsp_set_state(adsp_engine* engine, const void* host_history);
 
 /* Kernel timing for benchmarks: when enabled, every launch of the filter kernel is bracketed by a pair

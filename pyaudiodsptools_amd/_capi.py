@@ -77,6 +77,8 @@ SIGNATURES = {
                                        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "adsp_mix_host": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
                                      ctypes.c_void_p, ctypes.c_size_t]),
+    "adsp_get_epilogue_state": (ctypes.c_int, [_engine_p, ctypes.POINTER(ctypes.c_longlong)]),
+    "adsp_set_epilogue_state": (ctypes.c_int, [_engine_p, ctypes.c_longlong]),
     "adsp_set_accumulate": (ctypes.c_int, [_engine_p, ctypes.c_int]),
     "adsp_scan_create_biquad": (ctypes.c_int, [ctypes.POINTER(AdspScanConfig), ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
     "adsp_scan_create_compressor": (ctypes.c_int, [ctypes.POINTER(AdspScanConfig), ctypes.c_float, ctypes.c_void_p, ctypes.c_int,

@@ -836,6 +836,21 @@ int adsp_effect_host(int device_id, int effect, float p0, float p1, float p2, in
     return ADSP_OK;
 }
 
+int adsp_get_epilogue_state(const adsp_engine* e, long long* state) {
+    if (!e || !state) return fail(ADSP_ERR_ARG, "NULL argument");
+    *state = e->lfo_copy_len;  // the fused tremolo's whole state: the length of the reference's LFO buffer
+    return ADSP_OK;
+}
+
+int adsp_set_epilogue_state(adsp_engine* e, long long state) {
+    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    if (e->epi_op != ADSP_EFFECT_TREMOLO) return state == 0 ? ADSP_OK : fail(ADSP_ERR_STATE, "only a fused tremolo carries state");
+    if (state < 1 || state > (long long)e->lfo_len + e->cfg.chunk_size)
+        return fail(ADSP_ERR_ARG, "tremolo state %lld out of range 1..%lld", state, (long long)e->lfo_len + e->cfg.chunk_size);
+    e->lfo_copy_len = state;
+    return ADSP_OK;
+}
+
 int adsp_set_accumulate(adsp_engine* e, int mode) {
     if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
     if (mode < 0 || mode > 2) return fail(ADSP_ERR_ARG, "accumulate mode must be 0, 1 or 2");

@@ -123,6 +123,15 @@ class FirEngine:
         _capi.check(self._lib.adsp_get_state(self._h, _ptr(out)))
         return out
 
+    def get_epilogue_state(self):
+        """What a fused effect adds to a checkpoint (the tremolo's LFO position; 0 for stateless effects)."""
+        v = ctypes.c_longlong(0)
+        _capi.check(self._lib.adsp_get_epilogue_state(self._h, ctypes.byref(v)))
+        return v.value
+
+    def set_epilogue_state(self, state):
+        _capi.check(self._lib.adsp_set_epilogue_state(self._h, int(state)))
+
     def set_state(self, history):
         h = np.ascontiguousarray(history, dtype=self.dtype)
         if h.shape != (self.geometry.history_chunks, self.channels, self.chunk_size):

@@ -238,6 +238,37 @@ def test_fused_tremolo_matches_reference_chain(adsp, golden, name, make, depth, 
         assert_parity(d_out.cpu().numpy().reshape(-1), want, what=f"{name} split {split}")
 
 
+def test_fused_tremolo_reset_and_checkpoint(adsp, golden):
+    """adsp_reset restarts a fused tremolo's LFO with the filter history (the reference pair: fresh filter + fresh
+    CreateTremolo); history + adsp_get/set_epilogue_state carry a running stream into a second engine."""
+    n, chunks = 512, 12
+    adsp.config.initialize(44100, n)
+    x = seeded_stream(106, chunks * n)
+    want = golden["kat_effects"]["chain512_lowcut_tremolo"]
+    dev = adsp.CreateLowCutFilter(200)
+    dev.engine.set_epilogue(adsp.CreateTremolo(0.6, 10))
+    for i in range(5):
+        dev.apply(x[i * n:(i + 1) * n])
+    dev.reset()  # no new set_epilogue: the LFO must start over by itself
+    got = np.concatenate([dev.apply(x[i * n:(i + 1) * n]) for i in range(chunks)])
+    assert_parity(got, want, what="fused tremolo after reset")
+    # checkpoint after 7 chunks, resume in a fresh engine
+    dev.reset()
+    first = [dev.apply(x[i * n:(i + 1) * n]) for i in range(7)]
+    hist, lfo = dev.engine.get_state(), dev.engine.get_epilogue_state()
+    assert lfo > 0
+    other = adsp.CreateLowCutFilter(200)
+    other.engine.set_epilogue(adsp.CreateTremolo(0.6, 10))
+    other.engine.set_state(hist)
+    other.engine.set_epilogue_state(lfo)
+    rest = [other.apply(x[i * n:(i + 1) * n]) for i in range(7, chunks)]
+    assert_parity(np.concatenate(first + rest), want, what="fused tremolo across a checkpoint")
+    plain = adsp.CreateLowCutFilter(200)
+    assert plain.engine.get_epilogue_state() == 0
+    with pytest.raises(RuntimeError):
+        plain.engine.set_epilogue_state(5)  # nothing to carry without a fused tremolo
+
+
 def test_fused_tremolo_many_channels_ring_and_generic_geometry(adsp):
     """[steps, C, N] batches on the specialised and the generic kernel, and the zero-copy ring path, against the oracle."""
     import torch
