@@ -25,7 +25,10 @@
 //    v_permlane32_swap.  Either way split + spectrum multiply + re-pack is ONE 2x2 complex matrix per bin
 //    pair (pair_op, 16 multiply-adds) and needs no LDS exchange.
 //  * inverse FFT = forward FFT on (im, re)-swapped registers: one set of butterflies, one sign.
-//  * radix-16 pass twiddles are two-level: 6 loaded, 9 formed in registers (w^(4a+b) = w^(4a) w^b).
+//  * radix-16 pass twiddles are two-level: 6 loaded, 9 formed in registers (w^(4a+b) = w^(4a) w^b); radix-32 passes
+//    likewise (10 loaded, 21 formed).
+//  * the large transforms (M = 8192, 16384) run their LDS exchanges in two rounds over HALF a buffer (Plan::HALF), which
+//    is what lets a third / second workgroup onto the CU (one M = 16384 transform used to own the CU's LDS and registers).
 //  * global accesses are 16 bytes per lane (8 for int16 PCM) with a DPP swap between neighbouring lanes -
 //    a dwordx2 costs the TA exactly what a dwordx4 does; chunk selection (ring history vs. the new batch)
 //    is resolved once per block into <= F/N + 1 pointers; output stores are non-temporal.
