@@ -98,3 +98,76 @@ def test_random_geometry_and_call_pattern_against_the_exact_engine(seed):
     what = f"seed {seed}: N={n} {kind} taps={len(fir.taps)} C={channels} steps={steps} F={eng.geometry.fft_size} V={eng.block_outputs} {opt} ring={ring}"
     assert bool(torch.isfinite(y).all()), what
     assert err <= 1e-5 * max(scale, 0.1), f"{what}: max|d| = {err:.3e}, scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_int16_engines_against_the_exact_engine(seed):
+    """int16 PCM batches (the S16 kernel instantiations of every plan, the large half-exchange ones included): never more
+    than one LSB from the exact engine's int16 stream, and rarely."""
+    import torch
+    import pyaudiodsptools_amd as adsp
+    from pyaudiodsptools_amd import FirEngine, design
+    rng, n, fir, channels, steps, kind = make_case(300 + seed)
+    if not design.fits_one_transform(fir):
+        pytest.skip("kernel longer than one transform")
+    opt = str(rng.choice(["stream", "batch"]))
+    eng = FirEngine(fir, channels=channels, optimize_for=opt, sample_format="s16")
+    amp = 8000 if kind in ("eq", "chain", "chain_full") else 30000  # EQ gains up to +6 dB per band: keep clear of int16 overflow
+    x = torch.randint(-amp, amp, (steps, channels, n), device="cuda", dtype=torch.int16,
+                      generator=torch.Generator(device="cuda").manual_seed(seed))
+    y = torch.zeros_like(x)
+    s = torch.cuda.current_stream().cuda_stream
+    k = 0
+    while k < steps:
+        cnt = int(rng.integers(1, steps - k + 1))
+        eng.apply_device(x[k:k + cnt], y[k:k + cnt], cnt, s)
+        k += cnt
+    ex = adsp.ExactFirEngine(fir, channels=channels, sample_format="s16")
+    truth = torch.empty_like(x)
+    ex.apply_device(x, truth, steps, s)
+    torch.cuda.synchronize()
+    d = (y.int() - truth.int()).abs()
+    what = f"seed {seed}: N={n} {kind} taps={len(fir.taps)} C={channels} steps={steps} F={eng.geometry.fft_size} {opt}"
+    assert int(d.max()) <= 1, f"{what}: {int(d.max())} LSB"
+    assert float((d != 0).float().mean()) <= 0.01, f"{what}: {100 * float((d != 0).float().mean()):.2f} % of the samples differ"
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_fused_volume_and_accumulate_against_the_exact_engine(seed):
+    """The EPI kernel instantiations of every plan: a fused VolumeChange with clipping on the output registers, and the
+    accumulating output modes (add to what the buffer holds; add and clip = MixSignals), against the exact engine."""
+    import torch
+    import pyaudiodsptools_amd as adsp
+    from pyaudiodsptools_amd import FirEngine, design
+    rng, n, fir, channels, steps, kind = make_case(600 + seed)
+    if not design.fits_one_transform(fir):
+        pytest.skip("kernel longer than one transform")
+    opt = str(rng.choice(["stream", "batch"]))
+    eng = FirEngine(fir, channels=channels, optimize_for=opt)
+    db = float(rng.uniform(-3, 9))
+    mode = int(rng.choice([0, 1, 2]))
+    adsp.config.initialize(44100, n)
+    eng.set_epilogue(adsp.CreateVolumeChange(db))
+    eng.set_accumulate(mode)
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=gen)
+    base = torch.empty_like(x).uniform_(-0.5, 0.5, generator=gen)
+    y = base.clone()
+    s = torch.cuda.current_stream().cuda_stream
+    k = 0
+    while k < steps:
+        cnt = int(rng.integers(1, steps - k + 1))
+        eng.apply_device(x[k:k + cnt], y[k:k + cnt], cnt, s)
+        k += cnt
+    ex = adsp.ExactFirEngine(fir, channels=channels)
+    truth = torch.empty_like(x)
+    ex.apply_device(x, truth, steps, s)
+    torch.cuda.synchronize()
+    want = (truth * (10 ** (db / 20))).clamp(-1, 1)   # VolumeChange clips (Utility.py:189-194)
+    if mode >= 1:
+        want = want + base
+    if mode == 2:
+        want = want.clamp(-1, 1)
+    what = f"seed {seed}: N={n} {kind} taps={len(fir.taps)} C={channels} steps={steps} F={eng.geometry.fft_size} {opt} mode={mode} {db:.2f} dB"
+    scale = max(float(truth.abs().max()) * 10 ** (db / 20), 0.1)
+    assert float((y - want).abs().max()) <= 1e-5 * max(scale, 1.0), f"{what}: {float((y - want).abs().max()):.3e}"
