@@ -309,16 +309,22 @@ struct Pass {
     }
 
     // two-level twiddle rows of a one-butterfly pass, loadable long before the pass runs (they depend on tid only)
-    static constexpr bool PREFETCHABLE = ADSP_TW_PREFETCH && S > 1 && PL::tw_two_level(R, S) && NB == 1;
+#ifndef ADSP_TW_PREFETCH_NB
+#define ADSP_TW_PREFETCH_NB 1
+#endif
+    static constexpr bool PREFETCHABLE = ADSP_TW_PREFETCH && S > 1 && PL::tw_two_level(R, S) && NB <= ADSP_TW_PREFETCH_NB;
     static constexpr int TWROWS = PL::tw_rows2(R, S);  // table rows of a two-level pass (3 for radix 16, 5 for radix 32)
     struct Tw3 {
-        float4 t[5];
+        float4 t[NB < 1 ? 1 : NB][5];
     };
     static __device__ __forceinline__ Tw3 prefetch(const float4* __restrict__ tw, int tid, int ja, int jb) {
-        const int jlo = bfly(0, tid, ja, jb) & (S - 1);
         Tw3 r;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) r.t[k] = k < TWROWS ? tw[TWOFF + k * S + jlo] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < NB; ++i) {
+            const int jlo = bfly(i, tid, ja, jb) & (S - 1);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) r.t[i][k] = k < TWROWS ? tw[TWOFF + k * S + jlo] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         return r;
     }
 
@@ -342,7 +348,7 @@ struct Pass {
 #else
                 if constexpr (PREFETCHABLE) {
 #pragma unroll
-                    for (int k = 0; k < TWROWS; ++k) t[k] = pre->t[k];
+                    for (int k = 0; k < TWROWS; ++k) t[k] = pre->t[i][k];
                 } else {
 #pragma unroll
                     for (int k = 0; k < TWROWS; ++k) t[k] = tw[TWOFF + k * S + jlo];
