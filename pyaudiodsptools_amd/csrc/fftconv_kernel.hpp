@@ -309,10 +309,10 @@ struct Pass {
     }
 
     // two-level twiddle rows of a one-butterfly pass, loadable long before the pass runs (they depend on tid only)
-#ifndef ADSP_TW_PREFETCH_NB
-#define ADSP_TW_PREFETCH_NB 1
-#endif
-    static constexpr bool PREFETCHABLE = ADSP_TW_PREFETCH && S > 1 && PL::tw_two_level(R, S) && NB <= ADSP_TW_PREFETCH_NB;
+    // ... of one-butterfly passes, and of the two-butterfly passes of the 32-points-per-thread plans (M = 8192: +3 %; at 16
+    // points per thread the extra 24 registers buy nothing, at 64 they spill: -5 %)
+    static constexpr bool PREFETCHABLE =
+        ADSP_TW_PREFETCH && S > 1 && PL::tw_two_level(R, S) && (NB == 1 || (NB == 2 && PL::P == 32));
     static constexpr int TWROWS = PL::tw_rows2(R, S);  // table rows of a two-level pass (3 for radix 16, 5 for radix 32)
     struct Tw3 {
         float4 t[NB < 1 ? 1 : NB][5];
