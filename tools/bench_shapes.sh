@@ -5,7 +5,7 @@ run "lowcut N=512  x32768" "--chunk 512 --channels 32768"
 run "lowcut N=1024 x16384" "--chunk 1024 --channels 16384"
 run "lowcut N=2048 x8192" "--chunk 2048 --channels 8192"
 run "lowcut N=8192 x2048" "--chunk 8192 --channels 2048"
-run "highcut N=4096 x8192 (config 4 per GPU)" "--filter highcut --channels 8192 --chunks-per-step 48"
+run "highcut N=4096 x8192 (config 4 per GPU)" "--filter highcut --channels 8192"
 run "eq3 N=512 x4096 (config 3)" "--filter eq3 --chunk 512 --channels 4096"
 run "eq3 N=4096 x4096" "--filter eq3"
 run "chain N=8192 x4096 96k (config 5 per GPU)" "--filter chain --chunk 8192 --fs 96000 --channels 4096 --chunks-per-step 44"
