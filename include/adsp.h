@@ -41,7 +41,7 @@ extern "C" {
 #define ADSP_API
 #endif
 
-#define ADSP_ABI_VERSION 4
+#define ADSP_ABI_VERSION 5
 #define ADSP_MAX_HISTORY 8
 
 typedef enum adsp_status {

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADSP_LIB") or os.path.join(_HERE, "libadsp.so")  # ADSP_LIB: tuning builds only
 
-ADSP_ABI_VERSION = 4
+ADSP_ABI_VERSION = 5
 ADSP_MAX_HISTORY = 8
 ADSP_FORMAT_F32, ADSP_FORMAT_S16 = 0, 1
 EFFECT_NONE, EFFECT_VOLUME, EFFECT_SOFT_CLIPPER, EFFECT_HARD_DISTORTION, EFFECT_SATURATOR, EFFECT_TREMOLO = 0, 1, 2, 3, 4, 5
