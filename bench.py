@@ -308,6 +308,7 @@ def main():
     if os.environ.get("ADSP_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
     backend = os.environ.get("ADSP_BENCH_BACKEND", "nccl")
+    local_rank %= torch.cuda.device_count()  # a launcher that narrows HIP_VISIBLE_DEVICES per rank leaves one device, index 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     barrier = None
