@@ -345,12 +345,12 @@ int upload_pairs(adsp_engine* e, const float* H, hipStream_t stream, bool async 
     for (int r = 0; r < R / 2; ++r) put0(2 + (R / 2 - 1) + r, D / 2 + D * r);
     const size_t b1 = tab.size() * sizeof(float4), b0 = tab0.size() * sizeof(float2);
     if (async) {
-        if (!e->pin_tab[0]) {
+        if (e->pin_tab_bytes < b1 + b0) {  // first use (the table size of an engine never changes afterwards)
             for (int i = 0; i < 2; ++i) {
-                HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->pin_tab[i]), b1 + b0, hipHostMallocDefault));
-                HIP_TRY(hipEventCreateWithFlags(&e->ev_tab[i], hipEventDisableTiming));
+                if (!e->pin_tab[i]) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->pin_tab[i]), b1 + b0, hipHostMallocDefault));
+                if (!e->ev_tab[i]) HIP_TRY(hipEventCreateWithFlags(&e->ev_tab[i], hipEventDisableTiming));
             }
-            e->pin_tab_bytes = b1 + b0;
+            e->pin_tab_bytes = b1 + b0;  // only once both buffers and both events exist
         }
         const int b = e->tab_slot ^= 1;
         if (e->tab_busy[b]) HIP_TRY(hipEventSynchronize(e->ev_tab[b]));  // the copy two updates ago read this buffer

@@ -113,7 +113,7 @@ class FirStream:
         budget = 0.5 * float(eps) * a.sum()
         lo = int(np.searchsorted(np.cumsum(a), budget, side="right"))            # taps[:lo] weigh <= budget
         hi = len(a) - int(np.searchsorted(np.cumsum(a[::-1]), budget, side="right"))
-        if lo == 0 and hi == len(a):
+        if (lo == 0 and hi == len(a)) or hi - lo < 1:  # nothing to drop / a budget that would drop everything
             return self
         return FirStream(self.taps[lo:hi], self.chunk_size, self.latency_chunks, self.lookahead - lo)
 
