@@ -204,3 +204,52 @@ def test_config_mirror():
     assert (config.sampling_rate, config.chunk_size, config.use_gpu) == (48000, 1024, False)
     config.initialize(44100, 512, use_gpu=True)
     assert (config.sampling_rate, config.chunk_size, config.use_gpu) == (44100, 512, True)
+
+
+def test_geometry_invariants_and_host_overlap_save_for_random_kernels():
+    """design.overlap_save_geometry for 150 random kernels (lengths, delays, symmetric or not, power-of-two and arbitrary
+    chunk sizes, stream and batch): alignment rules of include/adsp.h hold, and the overlap-save arithmetic executed with
+    numpy's rfft (window tail zeroed where the kernel would skip it) equals the float64 direct convolution."""
+    from pyaudiodsptools_amd import _capi, design
+    from oracle import fftfilter_oracle as o
+    rng = np.random.default_rng(2024)
+    done = 0
+    while done < 150:
+        n = int(rng.choice([64, 128, 256, 512, 1024, 2048, 100, 360, 1000, 1920]))
+        m = int(rng.integers(1, n))
+        sym = rng.random() < 0.4
+        taps = rng.normal(size=m)
+        if sym:
+            taps = taps + taps[::-1]
+        latency = int(rng.integers(1, 3))
+        lookahead = int(rng.integers(0, n // 2))
+        fir = design.FirStream(taps / max(np.abs(taps).sum(), 1e-9), n, latency, lookahead)
+        opt = str(rng.choice(["stream", "batch"]))
+        try:
+            geo = design.overlap_save_geometry(fir, 0, opt)
+        except ValueError:
+            continue
+        done += 1
+        pow2 = n & (n - 1) == 0
+        f, g = geo.fft_size, (n // 4 if pow2 else 4)
+        reach = max(0, -geo.shift)
+        assert f & (f - 1) == 0 and 128 <= f <= 32768
+        assert geo.lookback % g == 0 and 0 < geo.lookback <= geo.history_chunks * n <= _capi.ADSP_MAX_HISTORY * n
+        assert geo.out_offset % g == 0 and geo.out_offset <= geo.lookback
+        assert geo.max_block_outputs >= (n if pow2 else 1) and geo.out_offset + geo.max_block_outputs <= f - reach
+        # circular placement: no tap wraps into the kept slice
+        assert geo.out_offset >= geo.shift + m - 1 if geo.shift >= 0 else geo.out_offset >= reach
+        spec = design.engine_spectrum(fir, geo).view(np.complex64).astype(np.complex128)
+        chunks = 5
+        x = rng.uniform(-1, 1, chunks * n)
+        truth = o.direct_stream_convolution(fir.taps, x, n, fir.latency_chunks, fir.lookahead)
+        padded = np.concatenate([np.zeros(geo.history_chunks * n), x, np.zeros(f)])
+        v = n if (opt == "stream" and pow2) else geo.max_block_outputs
+        out = np.zeros(chunks * n + v)
+        for ob in range(0, chunks * n, v):
+            a = ob - geo.lookback + geo.history_chunks * n
+            win = padded[a:a + f].copy()
+            win[geo.out_offset + v + reach:] = 0.0
+            out[ob:ob + v] = np.fft.irfft(np.fft.rfft(win) * spec, f)[geo.out_offset:geo.out_offset + v]
+        err = np.abs(out[:chunks * n] - truth).max()
+        assert err <= 2e-6 * max(np.abs(truth).max(), 1e-3) + 1e-7, (n, m, sym, latency, lookahead, opt, geo, err)
