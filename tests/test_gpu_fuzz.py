@@ -4,11 +4,13 @@ end-tap trimming, arbitrary asymmetric kernels), channel counts, transform lengt
 (single-step, multi-step, zero-copy ring, host buffers) - every output sample of every channel, 1e-5 of full scale.
 Seeds are fixed: a failure names its case.  Run with -m gpu on MI355X."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+SCALE = int(os.environ.get("ADSP_FUZZ_SCALE", "1"))  # ADSP_FUZZ_SCALE=10: ten times as many seeded cases (soak runs)
 
 POW2 = [64, 128, 256, 512, 1024, 2048, 4096, 8192]
 OTHER = [20, 100, 360, 1000, 1920, 3000, 4400, 12000]
@@ -45,7 +47,7 @@ def make_case(seed):
     return rng, n, fir, channels, steps, kind
 
 
-@pytest.mark.parametrize("seed", range(200))
+@pytest.mark.parametrize("seed", range(200 * SCALE))
 def test_random_geometry_and_call_pattern_against_the_exact_engine(seed):
     import torch
     import pyaudiodsptools_amd as adsp
@@ -100,7 +102,7 @@ def test_random_geometry_and_call_pattern_against_the_exact_engine(seed):
     assert err <= 1e-5 * max(scale, 0.1), f"{what}: max|d| = {err:.3e}, scale {scale:.3e}"
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(60 * SCALE))
 def test_random_int16_engines_against_the_exact_engine(seed):
     """int16 PCM batches (the S16 kernel instantiations of every plan, the large half-exchange ones included): never more
     than one LSB from the exact engine's int16 stream, and rarely."""
@@ -132,7 +134,7 @@ def test_random_int16_engines_against_the_exact_engine(seed):
     assert float((d != 0).float().mean()) <= 0.01, f"{what}: {100 * float((d != 0).float().mean()):.2f} % of the samples differ"
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(60 * SCALE))
 def test_random_fused_volume_and_accumulate_against_the_exact_engine(seed):
     """The EPI kernel instantiations of every plan: a fused VolumeChange with clipping on the output registers, and the
     accumulating output modes (add to what the buffer holds; add and clip = MixSignals), against the exact engine."""
