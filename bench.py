@@ -79,6 +79,9 @@ def parse(argv=None):
     ap.add_argument("--no-stream-extra", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="stream mode: do not try the hipGraph replay")
+    ap.add_argument("--streams", type=int, default=1, help="stream mode: issue consecutive steps on this many HIP streams in turn "
+                    "(a step depends on the ring, not on the previous step's kernel: two streams let the next launch fill the "
+                    "CUs the previous one is draining)")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="per CPU-baseline measurement (four of them)")
     a = ap.parse_args(argv)
     if a.mode == "offline":
@@ -164,12 +167,20 @@ class Runner:
             self.cps = 1
             self.samples_per_step = C * N
 
-            def run(k_steps, sp=sptr):
-                for i in range(k_steps):
-                    eng.apply_ring(self.outs[i % 4], sp)
+            side = [torch.cuda.Stream(device=dev) for _ in range(max(0, args.streams - 1))]
+            self.side_streams = side
+            sps = [sptr] + [st.cuda_stream for st in side]
+
+            def run(k_steps, sp=None):
+                if sp is not None or len(sps) == 1:
+                    for i in range(k_steps):
+                        eng.apply_ring(self.outs[i % 4], sp if sp is not None else sptr)
+                else:  # consecutive steps on alternating streams
+                    for i in range(k_steps):
+                        eng.apply_ring(self.outs[i % 4], sps[i % len(sps)])
             self._launch_steps = run
             self.graph_steps = 0
-            if not args.no_graph:
+            if not args.no_graph and args.streams == 1:
                 self._try_graph(12 * eng.ring_slots)
 
             def run_any(k_steps):
@@ -205,7 +216,7 @@ class Runner:
             g = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream()
             with torch.cuda.graph(g, stream=side):
-                self._launch_steps(steps_per_replay, torch.cuda.current_stream().cuda_stream)
+                self._launch_steps(steps_per_replay, torch.cuda.current_stream().cuda_stream)  # explicit stream: the capture stream
             torch.cuda.synchronize()
             g.replay()
             torch.cuda.synchronize()
@@ -273,6 +284,21 @@ def stream_figures(args, fir, dev, local_rank, world, rank, alg_bytes, channels=
         out["graph"] = {"error": r.graph_error}
     del r
     torch.cuda.empty_cache()
+    if args.streams == 1 and not getattr(args, "no_two_streams", False):
+        try:  # the same launches, consecutive steps on two HIP streams in turn
+            import copy
+            a2 = copy.copy(args)
+            a2.streams, a2.no_graph = 2, True
+            r2 = Runner(a2, "stream", fir, dev, local_rank, world, rank, channels, chunk)
+            t_steps, _, t_wall, _, _ = r2.measure(steps, steps // 4, None, args.prewarm_ms / 3, time_kernels=False)
+            out["two_streams"] = {"value": round(C * N * t_steps / t_wall / 1e6, 1), "us_per_step": round(t_wall / t_steps * 1e6, 2),
+                                  "roofline_frac": round(alg_bytes * C * N * t_steps / t_wall / 1e9 / HBM_PEAK_GBS, 4),
+                                  "note": "consecutive steps issued on two HIP streams in turn: a step depends on the ring, not on the "
+                                          "previous step's kernel, so the next launch fills the CUs the previous one is draining"}
+            del r2
+            torch.cuda.empty_cache()
+        except Exception as exc:
+            out["two_streams"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
     return out
 
 
