@@ -180,7 +180,8 @@ class Runner:
                         eng.apply_ring(self.outs[i % 4], sps[i % len(sps)])
             self._launch_steps = run
             self.graph_steps = 0
-            if not args.no_graph and args.streams == 1:
+            self.nstreams = max(1, args.streams)
+            if not args.no_graph:
                 self._try_graph(12 * eng.ring_slots)
 
             def run_any(k_steps):
@@ -209,14 +210,23 @@ class Runner:
 
     def _try_graph(self, steps_per_replay):
         """Capture `steps_per_replay` consecutive single-step launches (a multiple of the ring length, so the ring
-        position is back where it started) into one hipGraph: same kernels, same arguments, no per-launch host cost."""
+        position is back where it started) into one hipGraph: same kernels, same arguments, no per-launch host cost.
+        With --streams 2 the capture forks: consecutive steps alternate between two captured streams, so the graph holds
+        two independent chains of launches."""
         torch = self.torch
         try:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream()
             with torch.cuda.graph(g, stream=side):
-                self._launch_steps(steps_per_replay, torch.cuda.current_stream().cuda_stream)  # explicit stream: the capture stream
+                cur = torch.cuda.current_stream()
+                branches = [cur] + [torch.cuda.Stream() for _ in range(self.nstreams - 1)]
+                for b in branches[1:]:
+                    b.wait_stream(cur)  # fork: the branch joins the capture
+                for i in range(steps_per_replay):
+                    self.eng.apply_ring(self.outs[i % 4], branches[i % len(branches)].cuda_stream)
+                for b in branches[1:]:
+                    cur.wait_stream(b)  # join
             torch.cuda.synchronize()
             g.replay()
             torch.cuda.synchronize()
@@ -288,13 +298,19 @@ def stream_figures(args, fir, dev, local_rank, world, rank, alg_bytes, channels=
         try:  # the same launches, consecutive steps on two HIP streams in turn
             import copy
             a2 = copy.copy(args)
-            a2.streams, a2.no_graph = 2, True
+            a2.streams = 2
             r2 = Runner(a2, "stream", fir, dev, local_rank, world, rank, channels, chunk)
             t_steps, _, t_wall, _, _ = r2.measure(steps, steps // 4, None, args.prewarm_ms / 3, time_kernels=False)
             out["two_streams"] = {"value": round(C * N * t_steps / t_wall / 1e6, 1), "us_per_step": round(t_wall / t_steps * 1e6, 2),
                                   "roofline_frac": round(alg_bytes * C * N * t_steps / t_wall / 1e9 / HBM_PEAK_GBS, 4),
                                   "note": "consecutive steps issued on two HIP streams in turn: a step depends on the ring, not on the "
                                           "previous step's kernel, so the next launch fills the CUs the previous one is draining"}
+            if r2.graph is not None:
+                g_steps = -(-steps // r2.graph_steps) * r2.graph_steps
+                g_steps, _, g_wall, _, _ = r2.measure(g_steps, r2.graph_steps, None, args.prewarm_ms / 3, time_kernels=False, graph=True)
+                out["two_streams"]["graph"] = {"value": round(C * N * g_steps / g_wall / 1e6, 1), "us_per_step": round(g_wall / g_steps * 1e6, 2),
+                                               "roofline_frac": round(alg_bytes * C * N * g_steps / g_wall / 1e9 / HBM_PEAK_GBS, 4),
+                                               "note": "the same as a hipGraph with two independent chains of launches"}
             del r2
             torch.cuda.empty_cache()
         except Exception as exc:
