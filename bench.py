@@ -273,6 +273,7 @@ def stream_figures(args, fir, dev, local_rank, world, rank, alg_bytes, channels=
     import torch
     r = Runner(args, "stream", fir, dev, local_rank, world, rank, channels, chunk)
     C, N = r.C, r.N
+    r_slots = r.eng.ring_slots
     # wall clock without the per-launch timing events (two event records per launch are visible there), then a
     # shorter pass with them for the kernel duration
     s_steps, _, s_wall, _, _ = r.measure(steps, steps // 4, None, args.prewarm_ms, time_kernels=False)
@@ -299,6 +300,7 @@ def stream_figures(args, fir, dev, local_rank, world, rank, alg_bytes, channels=
             import copy
             a2 = copy.copy(args)
             a2.streams = 2
+            a2.ring_slots = args.ring_slots or r_slots + 1  # history + 2: what makes the two-stream pattern race-free (adsp.h)
             r2 = Runner(a2, "stream", fir, dev, local_rank, world, rank, channels, chunk)
             t_steps, _, t_wall, _, _ = r2.measure(steps, steps // 4, None, args.prewarm_ms / 3, time_kernels=False)
             out["two_streams"] = {"value": round(C * N * t_steps / t_wall / 1e6, 1), "us_per_step": round(t_wall / t_steps * 1e6, 2),
@@ -391,7 +393,7 @@ def main():
             a3 = parse(["--filter", "eq3", "--chunk", "512", "--fs", "44100", "--channels", "4096"] + (["--no-graph"] if args.no_graph else []))
             a3.prewarm_ms = min(args.prewarm_ms, 100.0)
             s3 = stream_figures(a3, make_fir(a3), dev, local_rank, world, rank, ALG_BYTES_PER_SAMPLE, steps=4096)
-            latency = {"config3_eq3_2048_stereo_pairs_x_512": {k: s3[k] for k in ("us_per_step", "avg_kernel_us", "value", "roofline_frac", "graph") if k in s3},
+            latency = {"config3_eq3_2048_stereo_pairs_x_512": {k: s3[k] for k in ("us_per_step", "avg_kernel_us", "value", "roofline_frac", "graph", "two_streams") if k in s3},
                        "numpy_api_apply_us_per_call": round(numpy_api_latency(), 2),
                        "note": "config 3 = CreateEQ3BandFFT(100,2,700,-4,8000,5) on 4096 mono channels (2048 stereo pairs) x 512 samples, one launch "
                                "per step (zero-copy ring); numpy API = CreateLowCutFilter(800).apply(float32[4096]) -> float32[4096], 1 channel, host "

@@ -679,6 +679,39 @@ def test_soak_mixed_call_types_ring_wrap(adsp, n, kind):
         assert_parity(y[:, c].reshape(-1), o.direct_stream_convolution(taps, x[:, c].reshape(-1), n), what=f"N={n} ch {c}")
 
 
+@pytest.mark.parametrize("n,kind", [(512, "eq"), (4096, "lowcut")])
+def test_two_stream_ring_pattern_with_a_real_producer(adsp, n, kind):
+    """include/adsp.h: consecutive ring steps on two HIP streams in turn, each step's producer (a device copy into the
+    ring slot) on the step's own stream, default ring length (2 x history = history + 2 slots): no extra synchronisation,
+    every channel equals the exact engine over 40 steps (the ring wraps ten times)."""
+    import ctypes
+    import torch
+    from pyaudiodsptools_amd import FirEngine, FirStream, design
+    fs, channels, steps = 44100, 96, 40
+    taps = design.lowcut_kernel(500, fs, n) if kind == "lowcut" else design.eq3_composite(100, 2, 700, -4, 8000, 5, fs, n)
+    fir = FirStream(taps, n)
+    eng = FirEngine(fir, channels=channels)  # ring_slots = 0 -> 2 x history
+    assert eng.ring_slots >= eng.geometry.history_chunks + 2
+    x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=torch.Generator(device="cuda").manual_seed(n))
+    y = torch.full_like(x, float("nan"))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    for k in range(steps):
+        s = streams[k % 2].cuda_stream
+        slot = eng.ring_acquire()
+        assert hip.hipMemcpyAsync(slot, x[k].data_ptr(), channels * n * 4, 3, s) == 0  # the producer, on the step's stream
+        eng.apply_ring(y[k], s)
+    torch.cuda.synchronize()
+    ex = adsp.ExactFirEngine(fir, channels=channels)
+    truth = torch.empty_like(x)
+    ex.apply_device(x, truth, steps, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(y).all())
+    assert float((y - truth).abs().max()) <= 1e-5 * float(truth.abs().max())
+
+
 @pytest.mark.parametrize("n,m,lookahead,expect_real", [
     (512, 255, 127, True),      # the reference's shape: delay + centre = N
     (512, 129, 64, True),       # shorter symmetric kernel, delay + centre = 512
