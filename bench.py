@@ -13,8 +13,9 @@ it; K steps = K launches over distinct resident batches.  (Round 1 counted singl
 `--steps 20` then timed a 0.8 ms region made of one ragged launch.  A step that is a whole batch makes the figure
 independent of K: 16 steps by default, 20 when the driver says so.)  `--mode stream` runs one launch per step over a
 [channels, chunk] batch through the zero-copy ring (adsp_apply_ring), the real-time call pattern; its figure is also
-measured (after the timed region) and reported under "stream" in the same line, launch by launch and replayed as a
-hipGraph.  History is carried by the engine exactly as between reference apply() calls; every output sample of every
+measured (after the timed region) and reported under "stream" in the same line: launch by launch, replayed as a
+hipGraph, and with consecutive steps on two HIP streams in turn ("two_streams": a step depends on the ring, not on the
+previous step's kernel).  History is carried by the engine exactly as between reference apply() calls; every output sample of every
 step is produced inside the timed region.  Before the W warmup steps the same workload runs untimed for --prewarm-ms
 (default 300 ms): an idle MI355X needs tens of milliseconds of sustained load before its shader clock has ramped up.
 
