@@ -1,6 +1,6 @@
 #!/bin/bash
 # batch and stream throughput of the other shapes quoted in DESIGN.md section 5 (GPU box); one line per shape
-run() { echo "$1 | $(python bench.py --no-cpu-baseline --no-latency --steps 8 --warmup 4 $2 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d.get("stream",{}); print("batch", d["value"], "frac", d["roofline"]["frac"], "| stream", s.get("value"), "frac", s.get("roofline_frac"), "| graph", s.get("graph",{}).get("value"), s.get("graph",{}).get("us_per_step"))')"; }
+run() { echo "$1 | $(python bench.py --no-cpu-baseline --no-latency --steps 8 --warmup 4 $2 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d.get("stream",{}); print("batch", d["value"], "frac", d["roofline"]["frac"], "| stream", s.get("value"), "frac", s.get("roofline_frac"), "| graph", s.get("graph",{}).get("value"), s.get("graph",{}).get("us_per_step"), "| two streams", s.get("two_streams",{}).get("value"), s.get("two_streams",{}).get("us_per_step"), s.get("two_streams",{}).get("roofline_frac"))')"; }
 run "lowcut N=512  x32768" "--chunk 512 --channels 32768"
 run "lowcut N=1024 x16384" "--chunk 1024 --channels 16384"
 run "lowcut N=2048 x8192" "--chunk 2048 --channels 8192"
