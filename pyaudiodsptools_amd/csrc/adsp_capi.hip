@@ -370,7 +370,7 @@ int upload_pairs(adsp_engine* e, const float* H, hipStream_t stream, bool async 
     return ADSP_OK;
 }
 
-int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream_t stream, int hist_copy = 0, int hist_slot0 = 0) {
+int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream_t stream) {
     const adsp_config& c = e->cfg;
     // same transform; the twin kernel has the output effect / mix bus compiled in (the plain generic kernel can add)
     const bool twin = e->epi_op != 0 || e->accumulate == 2 || (e->accumulate == 1 && !e->generic);
@@ -392,8 +392,6 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
     a.nh = c.history_chunks;
     a.inv_n = 1.0f / (float)c.chunk_size;
     a.accumulate = e->accumulate;
-    a.hist_copy = hist_copy;
-    a.hist_slot0 = hist_slot0;
     a.real_spec = e->real_spec ? 1 : 0;
     a.epi_phase = e->epi_phase;
     a.epi_replay = e->epi_replay;
@@ -911,35 +909,28 @@ int apply_device_run(adsp_engine* e, const void* d_in, void* d_out, int n_steps,
     const int cnt = n_steps < e->cfg.history_chunks ? n_steps : e->cfg.history_chunks;
     const size_t plane = e->plane_bytes();
     // The newest `cnt` chunks must end up in the ring.  They go to slots the kernel does not read when the ring has
-    // >= 2*history slots.  The specialised kernels then do it themselves (the workgroups of every channel's last block copy
-    // that channel's newest chunks: no extra launch, no re-read from HBM); the generic-geometry kernel leaves it to a
-    // device-to-device copy on a side stream BESIDE the kernel: it waits for the caller's input (event on `stream` before
-    // the launch) and the next launch on any stream waits for it (event after the copy).
-    const bool roomy = S >= 2 * e->cfg.history_chunks;
-    const bool in_kernel = roomy && !e->generic && e->cfg.chunk_size * (int)e->ssize() % (16 * e->plan->T) == 0 &&
-                           !getenv("ADSP_HOST_RING_COPY");  // (tuning: the round-1 path for A/B)
-    const bool side = roomy && n_steps > 1 && !in_kernel;
+    // >= 2*history slots, so the copy can run on a side stream BESIDE the kernel: it waits for the caller's input
+    // (event on `stream` before the launch) and the next launch on any stream waits for it (event after the copy).
+    const bool side = (S >= 2 * e->cfg.history_chunks) && n_steps > 1;
     if (e->copy_pending) {  // a previous side copy must have landed before this kernel reads the ring
         HIP_TRY(hipStreamWaitEvent(stream, e->ev_copy_done, 0));
         e->copy_pending = false;
     }
     if (side) HIP_TRY(hipEventRecord(e->ev_in_ready, stream));
-    if ((rc = launch(e, d_in, d_out, n_steps, stream, in_kernel ? cnt : 0, (e->ring_pos + 1) % S))) return rc;
-    if (!in_kernel) {
-        hipStream_t cs = side ? e->copy_stream : stream;
-        if (side) HIP_TRY(hipStreamWaitEvent(cs, e->ev_in_ready, 0));
-        for (int i = 0; i < cnt; ++i) {
-            const int slot = (e->ring_pos + 1 + i) % S;
-            const char* src = static_cast<const char*>(d_in) + (size_t)(n_steps - cnt + i) * plane;
-            HIP_TRY(hipMemcpyAsync(e->ring + (size_t)slot * plane, src, plane, hipMemcpyDefault, cs));  // src: device or mapped host
-        }
-        if (side) {
-            // join: everything the caller enqueues on `stream` after this call (and "stream finished => d_in may be
-            // reused") is ordered after the copy, while the copy still overlaps the kernel launched above.
-            HIP_TRY(hipEventRecord(e->ev_copy_done, cs));
-            HIP_TRY(hipStreamWaitEvent(stream, e->ev_copy_done, 0));
-            e->copy_pending = true;  // a later call on a DIFFERENT stream must also wait for it
-        }
+    if ((rc = launch(e, d_in, d_out, n_steps, stream))) return rc;
+    hipStream_t cs = side ? e->copy_stream : stream;
+    if (side) HIP_TRY(hipStreamWaitEvent(cs, e->ev_in_ready, 0));
+    for (int i = 0; i < cnt; ++i) {
+        const int slot = (e->ring_pos + 1 + i) % S;
+        const char* src = static_cast<const char*>(d_in) + (size_t)(n_steps - cnt + i) * plane;
+        HIP_TRY(hipMemcpyAsync(e->ring + (size_t)slot * plane, src, plane, hipMemcpyDefault, cs));  // src: device or mapped host
+    }
+    if (side) {
+        // join: everything the caller enqueues on `stream` after this call (and "stream finished => d_in may be
+        // reused") is ordered after the copy, while the copy still overlaps the kernel launched above.
+        HIP_TRY(hipEventRecord(e->ev_copy_done, cs));
+        HIP_TRY(hipStreamWaitEvent(stream, e->ev_copy_done, 0));
+        e->copy_pending = true;  // a later call on a DIFFERENT stream must also wait for it
     }
     e->ring_pos = (e->ring_pos + cnt) % S;
     return ADSP_OK;

@@ -91,9 +91,6 @@ struct KernelArgs {
     int win_pairs;         // register PAIRS of the window that are loaded (P/2 = all); the rest is taken as zero: window
                            // positions >= out_offset + V + (kernel taps at negative circular indices) only feed discarded
                            // outputs - a single-step launch of a zero-phase cut filter needs 1.5 N of its 2 N window
-    int hist_copy;         // > 0: the workgroups of each channel's LAST block also copy the newest `hist_copy` input chunks of
-    int hist_slot0;        // their channel into ring slots hist_slot0, +1, .. (mod ring_slots) - the history hand-over to the
-                           // next call, inside the launch (slots this launch does not read: ring_slots >= 2 * history)
     int accumulate;        // 1: add the kept samples to what `out` holds (partitioned FIRs, mixing); 2: and clip the sum
                            // to [-1, 1] (MixSignals).  Plain kernels: generic geometry + mode 1 only; EPI kernels: all.
 };
@@ -1242,23 +1239,6 @@ __global__ __launch_bounds__(PL::T* CPB, PL::MINW) void fftconv_kernel(const Ker
                 case 2: store_kept<PL, FN, 2, EPI>(ob, xr, xi, m_lo, m_hi, odd, a.accumulate); break;
                 default: store_kept<PL, FN, 3, EPI>(ob, xr, xi, m_lo, m_hi, odd, a.accumulate); break;
             }
-        }
-    }
-    // History hand-over: the newest chunks of this channel become the ring's newest slots (what the host used to do with
-    // a device-to-device copy beside the kernel: two copy kernels and 2 % more reads per launch).
-    if (a.hist_copy > 0 && blk == a.nblk - 1 && chan_ok) {
-        constexpr int CHUNK_BYTES = N * (S16 ? 2 : 4);
-        const size_t plane_bytes = static_cast<size_t>(a.C) * CHUNK_BYTES;
-        const size_t chan_bytes = static_cast<size_t>(c) * CHUNK_BYTES;
-        const char* src0 = static_cast<const char*>(a.in) + static_cast<size_t>(a.n_steps - a.hist_copy) * plane_bytes + chan_bytes;
-        char* ring_w = const_cast<char*>(static_cast<const char*>(a.ring));
-        for (int i = 0; i < a.hist_copy; ++i) {
-            int slot = a.hist_slot0 + i;
-            slot -= slot >= a.ring_slots ? a.ring_slots : 0;
-            const char* src = src0 + static_cast<size_t>(i) * plane_bytes;
-            char* dst = ring_w + static_cast<size_t>(slot) * plane_bytes + chan_bytes;
-            for (int off = tid * 16; off < CHUNK_BYTES; off += T * 16)
-                *reinterpret_cast<uint4*>(dst + off) = *reinterpret_cast<const uint4*>(src + off);
         }
     }
 }
