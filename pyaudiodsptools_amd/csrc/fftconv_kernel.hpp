@@ -61,11 +61,6 @@
 #define ADSP_MIN_WAVES 1
 #endif
 
-// ADSP_SETPRIO: wave priority (1..3) while a workgroup issues its window loads and its stores; 0 = leave priorities alone
-#ifndef ADSP_SETPRIO
-#define ADSP_SETPRIO 0
-#endif
-
 namespace adsp {
 
 struct KernelArgs {
@@ -1148,9 +1143,6 @@ __global__ __launch_bounds__(PL::T* CPB, PL::MINW) void fftconv_kernel(const Ker
     // blockIdx -> (channel group, time block).  Blocks b % 8 land on XCD b % 8 (observed, speed
     // only): keep one channel group's consecutive time blocks on one XCD so the overlapping part
     // of their windows is served by that XCD's L2.
-#if ADSP_SETPRIO
-    __builtin_amdgcn_s_setprio(ADSP_SETPRIO);  // a workgroup that is issuing its window loads goes first
-#endif
     const int lin = static_cast<int>(blockIdx.x);
     const int xcd = lin & 7;
     const int idx = lin >> 3;
@@ -1215,13 +1207,7 @@ __global__ __launch_bounds__(PL::T* CPB, PL::MINW) void fftconv_kernel(const Ker
         }
     }
 
-#if ADSP_SETPRIO
-    __builtin_amdgcn_s_setprio(0);  // the window is on its way: butterflies at normal priority
-#endif
     transform_block<PL>(xr, xi, lds, a, tid);
-#if ADSP_SETPRIO
-    __builtin_amdgcn_s_setprio(ADSP_SETPRIO);  // results first: their stores free the workgroup's slot
-#endif
     if constexpr (EPI) apply_epilogue<P, T>(xr, xi, a, blk * a.V - a.j0 + 2 * tid);  // separate instantiation: the plain kernel pays nothing
 
     // kept samples: circular indices [j0, j0 + keep) -> registers m_lo <= m < m_hi; register m holds
