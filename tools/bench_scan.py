@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Throughput of the per-channel scan kernels (IIR 3-band EQ cascade, compressor) on the headline batch shape; GPU box."""
+"""Throughput of the per-channel scan kernels (IIR 3-band EQ cascade, compressor, gate) on the headline batch shape; GPU box."""
 import json
 import os
 import sys
@@ -16,7 +16,8 @@ x = (torch.rand((STEPS, C, N), device="cuda") * 2 - 1) * 0.3
 y = torch.empty_like(x)
 eq = adsp.CreateEQ3Band(100, 2, 700, -4, 8000, 5, channels=C)
 cp = adsp.CreateCompressor(channels=C)
-for name, eng in (("iir_eq3_cascade", eq.cascade), ("iir_one_band", eq._low), ("compressor", cp.engine)):
+gt = adsp.CreateGate(channels=C)
+for name, eng in (("iir_eq3_cascade", eq.cascade), ("iir_one_band", eq._low), ("compressor", cp.engine), ("gate", gt.engine)):
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < 0.3:  # clock ramp
         eng.apply_device(x, y, STEPS)
