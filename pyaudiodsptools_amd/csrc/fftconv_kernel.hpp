@@ -12,15 +12,15 @@
 // points is exact and 3x cheaper.
 //
 // Design notes (CDNA4, all measured on MI355X - see DESIGN.md section 3/5 and micro/):
-//  * wave64; every thread owns P (16 or 32) complex points in VGPRs, element index tid + T*m.
+//  * wave64; every thread owns P (16, 32 or 64) complex points in VGPRs, element index tid + T*m.
 //    Every Stockham pass reads elements  j + q*M/R  (= the thread's own registers) and writes runs
 //    of S contiguous elements to LDS, so reads are always bank-conflict-free (64 consecutive
 //    8-byte elements per wave) and only the S=1 pass needs an XOR swizzle on the write side.
 //  * ds_read_b64/ds_write_b64 on interleaved (re,im) pairs; one LDS buffer of M*8 bytes per
 //    transform (32 KiB at N = 4096).
 //  * the real-FFT split needs Z[k] and Z[M-k] together.  In-register plans give the last forward pass
-//    (radix P/2, two butterflies per thread) butterflies j and M/R - j, so both partners are produced in
-//    the same thread; the "XL" plan (M = 4096: P = 16, 256 threads, three radix-16 passes) keeps one
+//    (radix P/2 with two butterflies per thread - or P/4 with four, .. - Plan::NBL) butterflies j and M/R - j, so both
+//    partners are produced in the same thread; the "XL" plan (M = 4096: P = 16, 256 threads, three radix-16 passes) keeps one
 //    butterfly per thread and exchanges half of the registers between lanes l and l^32 with
 //    v_permlane32_swap.  Either way split + spectrum multiply + re-pack is ONE 2x2 complex matrix per bin
 //    pair (pair_op, 16 multiply-adds) and needs no LDS exchange.
