@@ -253,3 +253,26 @@ def test_geometry_invariants_and_host_overlap_save_for_random_kernels():
             out[ob:ob + v] = np.fft.irfft(np.fft.rfft(win) * spec, f)[geo.out_offset:geo.out_offset + v]
         err = np.abs(out[:chunks * n] - truth).max()
         assert err <= 2e-6 * max(np.abs(truth).max(), 1e-3) + 1e-7, (n, m, sym, latency, lookahead, opt, geo, err)
+
+
+def _build_c_demo(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "capi_demo")
+    pkg = os.path.join(ROOT, "pyaudiodsptools_amd")
+    cmd = ["gcc", "-O2", "-std=c11", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "capi_demo.c"),
+           "-L" + pkg, "-ladsp", "-lm", "-Wl,-rpath," + pkg, "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    return exe
+
+
+def test_plain_c_program_links_against_the_abi_and_fails_loudly_without_a_gpu(tmp_path):
+    """examples/capi_demo.c: include/adsp.h is a C header (compiled as C11 with -Wall -Werror) and libadsp.so links from C.
+    Without a GPU the program stops at adsp_create with libadsp's message (there is no CPU fallback)."""
+    import subprocess
+    from pyaudiodsptools_amd import _capi
+    exe = _build_c_demo(tmp_path)
+    if _capi.device_count() >= 1:
+        pytest.skip("a GPU is visible: the run itself is tests/test_gpu_parity.py::test_plain_c_program_through_the_abi")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 2 and "adsp_create" in out.stderr and "no HIP device" in out.stderr

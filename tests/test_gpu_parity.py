@@ -679,6 +679,22 @@ def test_soak_mixed_call_types_ring_wrap(adsp, n, kind):
         assert_parity(y[:, c].reshape(-1), o.direct_stream_convolution(taps, x[:, c].reshape(-1), n), what=f"N={n} ch {c}")
 
 
+def test_plain_c_program_through_the_abi(adsp, tmp_path):
+    """examples/capi_demo.c - no Python between the caller and libadsp: the reference's LowCut(800) design restated in C,
+    3 channels x 8 chunks through adsp_apply_host, checked in C against the float64 direct convolution."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    pkg = os.path.join(ROOT, "pyaudiodsptools_amd")
+    exe = str(tmp_path / "capi_demo")
+    cmd = ["gcc", "-O2", "-std=c11", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "capi_demo.c"),
+           "-L" + pkg, "-ladsp", "-lm", "-Wl,-rpath," + pkg, "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "OK" in run.stdout and "real-spectrum stage 1" in run.stdout, run.stdout + run.stderr
+
+
 @pytest.mark.parametrize("n,kind", [(512, "eq"), (4096, "lowcut")])
 def test_two_stream_ring_pattern_with_a_real_producer(adsp, n, kind):
     """include/adsp.h: consecutive ring steps on two HIP streams in turn, each step's producer (a device copy into the
