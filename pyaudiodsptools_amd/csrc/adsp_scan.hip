@@ -202,18 +202,19 @@ struct Compressor {
     }
 };
 
-// One wave = 64 channels.  Time is walked in tiles of 64 samples: while the lanes run the recurrence over tile t
-// (each lane its own LDS row), the 64 row loads of tile t+1 are already in flight into registers - the recurrence is a
-// long dependent chain, the loads are the only latency that can be hidden, and there is one wave per 64 channels to
-// hide it with.
-template <class Op>
+// One wave = CH channels (4, 16 or 64: the host picks the smallest that still gives the chip a thousand waves - the
+// recurrence is a dependent chain of hundreds of cycles per sample, so what counts is how many SIMDs have a wave at all:
+// 4096 channels are 64 waves at 64 channels per wave and 1024 waves at 4, +4x measured).  Time is walked in tiles of 64
+// samples: while the first CH lanes run the recurrence over tile t (each its own LDS row), the CH row loads of tile t+1 are
+// already in flight into registers - the loads are the only latency a lone wave can hide.
+template <class Op, int CH>
 __global__ __launch_bounds__(TILE) void scan_kernel(const ScanArgs a) {
-    __shared__ float tile[TILE][TILE + 1];
+    __shared__ float tile[CH][TILE + 1];
     const int lane = static_cast<int>(threadIdx.x);
-    const int c0 = static_cast<int>(blockIdx.x) * TILE;
+    const int c0 = static_cast<int>(blockIdx.x) * CH;
     const int ch = c0 + lane;
-    const bool mine = ch < a.C;
-    const int rows = a.C - c0 < TILE ? a.C - c0 : TILE;
+    const bool mine = lane < CH && ch < a.C;
+    const int rows = a.C - c0 < CH ? a.C - c0 : CH;
     const int tiles_per_chunk = (a.N + TILE - 1) / TILE;
     const int n_tiles = a.n_steps * tiles_per_chunk;
     extern __shared__ float dyn_lds[];
@@ -227,19 +228,19 @@ __global__ __launch_bounds__(TILE) void scan_kernel(const ScanArgs a) {
         w = a.N - t0 < TILE ? a.N - t0 : TILE;
         return (static_cast<size_t>(s) * a.C + c0) * a.N + t0;
     };
-    float pre[TILE];
+    float pre[CH];
     auto fetch = [&](int t) {
         int w;
         const size_t base = tile_base(t, w);
 #pragma unroll
-        for (int r = 0; r < TILE; ++r) pre[r] = (r < rows && lane < w) ? a.in[base + static_cast<size_t>(r) * a.N + lane] : 0.f;
+        for (int r = 0; r < CH; ++r) pre[r] = (r < rows && lane < w) ? a.in[base + static_cast<size_t>(r) * a.N + lane] : 0.f;
     };
     fetch(0);
     for (int t = 0; t < n_tiles; ++t) {
         int w;
         const size_t base = tile_base(t, w);
 #pragma unroll
-        for (int r = 0; r < TILE; ++r) tile[r][lane] = pre[r];
+        for (int r = 0; r < CH; ++r) tile[r][lane] = pre[r];
         __syncthreads();
         if (t + 1 < n_tiles) fetch(t + 1);  // in flight during the recurrence below
         if (mine) {
@@ -252,6 +253,19 @@ __global__ __launch_bounds__(TILE) void scan_kernel(const ScanArgs a) {
         __syncthreads();
     }
     if (mine) op.save(a, ch);
+}
+
+template <class Op>
+void launch_scan(const ScanArgs& a, size_t dyn_lds, hipStream_t stream) {
+    // channels per wave: as few as it takes to put >= 1024 waves on the chip (256 CUs x 4 SIMDs)
+    const int ch = a.C >= 64 * 1024 ? 64 : a.C >= 16 * 1024 ? 16 : 4;
+    const unsigned grid = static_cast<unsigned>((a.C + ch - 1) / ch);
+    if (ch == 64)
+        hipLaunchKernelGGL((scan_kernel<Op, 64>), dim3(grid), dim3(TILE), dyn_lds, stream, a);
+    else if (ch == 16)
+        hipLaunchKernelGGL((scan_kernel<Op, 16>), dim3(grid), dim3(TILE), dyn_lds, stream, a);
+    else
+        hipLaunchKernelGGL((scan_kernel<Op, 4>), dim3(grid), dim3(TILE), dyn_lds, stream, a);
 }
 
 }  // namespace
@@ -395,20 +409,19 @@ int adsp_scan_apply_device(adsp_scan* e, const float* d_in, float* d_out, int n_
     a.x_max = e->x_max;
     a.y_max = e->y_max;
     a.cp_state = e->d_cp_state;
-    const unsigned grid = (unsigned)((a.C + TILE - 1) / TILE);
     const size_t env_bytes = ((size_t)e->x_max + (size_t)e->y_max) * sizeof(float);
     a.env_in_lds = (e->cfg.kind != ADSP_SCAN_BIQUAD && env_bytes <= 40 * 1024) ? 1 : 0;
     if (e->cfg.kind == ADSP_SCAN_BIQUAD) {
         switch (e->cfg.n_sections) {
-            case 1: hipLaunchKernelGGL(scan_kernel<Biquad<1>>, dim3(grid), dim3(TILE), 0, (hipStream_t)stream, a); break;
-            case 2: hipLaunchKernelGGL(scan_kernel<Biquad<2>>, dim3(grid), dim3(TILE), 0, (hipStream_t)stream, a); break;
-            case 3: hipLaunchKernelGGL(scan_kernel<Biquad<3>>, dim3(grid), dim3(TILE), 0, (hipStream_t)stream, a); break;
-            default: hipLaunchKernelGGL(scan_kernel<Biquad<4>>, dim3(grid), dim3(TILE), 0, (hipStream_t)stream, a); break;
+            case 1: launch_scan<Biquad<1>>(a, 0, (hipStream_t)stream); break;
+            case 2: launch_scan<Biquad<2>>(a, 0, (hipStream_t)stream); break;
+            case 3: launch_scan<Biquad<3>>(a, 0, (hipStream_t)stream); break;
+            default: launch_scan<Biquad<4>>(a, 0, (hipStream_t)stream); break;
         }
     } else if (a.env_in_lds)
-        hipLaunchKernelGGL(scan_kernel<Compressor<true>>, dim3(grid), dim3(TILE), env_bytes, (hipStream_t)stream, a);
+        launch_scan<Compressor<true>>(a, env_bytes, (hipStream_t)stream);
     else
-        hipLaunchKernelGGL(scan_kernel<Compressor<false>>, dim3(grid), dim3(TILE), 0, (hipStream_t)stream, a);
+        launch_scan<Compressor<false>>(a, 0, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return ADSP_OK;
 }
