@@ -84,10 +84,29 @@ def parse(argv=None):
                     "(a step depends on the ring, not on the previous step's kernel: two streams let the next launch fill the "
                     "CUs the previous one is draining)")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="per CPU-baseline measurement (four of them)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="drive all --gpus N devices from THIS process (one host thread and one engine per GPU); the filter is "
+                         "shared by adsp_bcast_spectrum (RCCL inside libadsp, ncclCommInitAll: no torch.distributed, no rendezvous). "
+                         "The driver's torchrun launch (one process per GPU) stays the default")
     a = ap.parse_args(argv)
     if a.mode == "offline":
         a.mode = "batch"
+    if os.environ.get("ADSP_BENCH_SMALL") == "1":
+        # test hook (tests/test_gpu_round3.py: two ranks on one GPU): a sixteenth of the channels, short batches.  The line
+        # says so ("small": true); never set by the driver
+        a.channels = max(64, a.channels // 16)
+        a.chunks_per_step = a.chunks_per_step or 12
+        a.small = True
     return a
+
+
+def kernel_sha16():
+    """Identity of the kernel sources a PMC traffic figure belongs to (profiles/traffic.json is stamped with it)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("fftconv_kernel.hpp", "plan_table.hpp"):
+        h.update(open(os.path.join(ROOT, "pyaudiodsptools_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def make_fir(args):
@@ -133,9 +152,16 @@ class Runner:
         from pyaudiodsptools_amd import design
         geo = design.overlap_save_geometry(fir, args.fft_mult, "stream" if stream_mode else "batch")
         slots = (args.ring_slots or geo.history_chunks + 1) if stream_mode else 0
-        self.bank = adist.ShardedFirBank(fir, C * world, device=local_rank, ring_slots=slots, fft_mult=args.fft_mult,
-                                         sample_format=args.io, optimize_for="stream" if stream_mode else "batch")
-        self.eng = eng = self.bank.engine
+        if getattr(args, "single_process", False):
+            # one process, many GPUs: plain engines, the filter is shared afterwards by adsp_bcast_spectrum (main())
+            from pyaudiodsptools_amd import FirEngine
+            self.bank = None
+            self.eng = eng = FirEngine(fir, channels=C, device=local_rank, ring_slots=slots, fft_mult=args.fft_mult,
+                                       sample_format=args.io, optimize_for="stream" if stream_mode else "batch")
+        else:
+            self.bank = adist.ShardedFirBank(fir, C * world, device=local_rank, ring_slots=slots, fft_mult=args.fft_mult,
+                                             sample_format=args.io, optimize_for="stream" if stream_mode else "batch")
+            self.eng = eng = self.bank.engine
         assert eng.channels == C
         if args.effect != "none":
             from pyaudiodsptools_amd import config, effects
@@ -176,8 +202,10 @@ class Runner:
                 if sp is not None or len(sps) == 1:
                     for i in range(k_steps):
                         eng.apply_ring(self.outs[i % 4], sp if sp is not None else sptr)
-                else:  # consecutive steps on alternating streams
+                else:  # consecutive steps on alternating streams; the (absent) producer's slot is acquired on the step's
+                    # stream, so the library's cross-stream ordering of the ring (adsp.h) is part of what is timed
                     for i in range(k_steps):
+                        eng.ring_acquire(sps[i % len(sps)])
                         eng.apply_ring(self.outs[i % 4], sps[i % len(sps)])
             self._launch_steps = run
             self.graph_steps = 0
@@ -217,6 +245,7 @@ class Runner:
         torch = self.torch
         try:
             torch.cuda.synchronize()
+            self.eng.ring_reset_order()  # ordering events of a capture and of live streams must not mix (adsp.h)
             g = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream()
             with torch.cuda.graph(g, stream=side):
@@ -225,10 +254,13 @@ class Runner:
                 for b in branches[1:]:
                     b.wait_stream(cur)  # fork: the branch joins the capture
                 for i in range(steps_per_replay):
+                    if len(branches) > 1:
+                        self.eng.ring_acquire(branches[i % len(branches)].cuda_stream)
                     self.eng.apply_ring(self.outs[i % 4], branches[i % len(branches)].cuda_stream)
                 for b in branches[1:]:
                     cur.wait_stream(b)  # join
             torch.cuda.synchronize()
+            self.eng.ring_reset_order()
             g.replay()
             torch.cuda.synchronize()
             self.graph, self.graph_steps = g, steps_per_replay
@@ -236,6 +268,7 @@ class Runner:
             self.graph, self.graph_steps, self.graph_error = None, 0, f"{type(exc).__name__}: {exc}"[:200]
             try:
                 torch.cuda.synchronize()
+                self.eng.ring_reset_order()
             except Exception:
                 pass
 
@@ -301,13 +334,13 @@ def stream_figures(args, fir, dev, local_rank, world, rank, alg_bytes, channels=
             import copy
             a2 = copy.copy(args)
             a2.streams = 2
-            a2.ring_slots = args.ring_slots or r_slots + 1  # history + 2: what makes the two-stream pattern race-free (adsp.h)
+            a2.ring_slots = args.ring_slots or r_slots + 1  # history + 2 slots: a producer may run one step further ahead
             r2 = Runner(a2, "stream", fir, dev, local_rank, world, rank, channels, chunk)
             t_steps, _, t_wall, _, _ = r2.measure(steps, steps // 4, None, args.prewarm_ms / 3, time_kernels=False)
             out["two_streams"] = {"value": round(C * N * t_steps / t_wall / 1e6, 1), "us_per_step": round(t_wall / t_steps * 1e6, 2),
                                   "roofline_frac": round(alg_bytes * C * N * t_steps / t_wall / 1e9 / HBM_PEAK_GBS, 4),
-                                  "note": "consecutive steps issued on two HIP streams in turn: a step depends on the ring, not on the "
-                                          "previous step's kernel, so the next launch fills the CUs the previous one is draining"}
+                                  "note": "consecutive steps issued on two HIP streams in turn, ordered through the ring by the library's per-step "
+                                          "events (adsp_ring_acquire_stream + adsp_apply_ring): the next launch fills the CUs the previous one is draining"}
             if r2.graph is not None:
                 g_steps = -(-steps // r2.graph_steps) * r2.graph_steps
                 g_steps, _, g_wall, _, _ = r2.measure(g_steps, r2.graph_steps, None, args.prewarm_ms / 3, time_kernels=False, graph=True)
@@ -343,7 +376,9 @@ def main():
     rank, local_rank, world = adist.env_world()
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
+    if args.single_process and world > 1:
+        raise SystemExit("--single-process drives every GPU from one process: do not launch it under torchrun")
+    if args.gpus > 1 and world == 1 and not args.single_process:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     if not torch.cuda.is_available():
@@ -365,12 +400,61 @@ def main():
     fir = make_fir(args)
     C, N = args.channels, args.chunk
     alg_bytes = ALG_BYTES_PER_SAMPLE if args.io == "f32" else 4
-    main_run = Runner(args, args.mode, fir, dev, local_rank, world, rank)
-    steps, warm, wall, kern_ms, launches = main_run.measure(args.steps, args.warmup, barrier, args.prewarm_ms)
-    if world > 1:
+    carrier = None
+    if args.single_process:
+        # ONE process, args.gpus devices: an engine and a host thread per GPU, the filter shared by adsp_bcast_spectrum
+        import threading
+        from pyaudiodsptools_amd.engine import broadcast_filter, rccl_version
+        ndev = args.gpus
+        if torch.cuda.device_count() < ndev:
+            raise SystemExit(f"--single-process --gpus {ndev}: only {torch.cuda.device_count()} devices visible")
+        runners = []
+        for i in range(ndev):
+            torch.cuda.set_device(i)
+            runners.append(Runner(args, args.mode, fir, torch.device("cuda", i), i, 1, i))
+        broadcast_filter([r.eng for r in runners], 0)
+        carrier = f"adsp_bcast_spectrum (RCCL {rccl_version()} inside libadsp, ncclCommInitAll over {ndev} device(s), one process)"
+        gate = threading.Barrier(ndev)
+        results, errors = [None] * ndev, []
+
+        def work(i):
+            try:
+                torch.cuda.set_device(i)
+                results[i] = runners[i].measure(args.steps, args.warmup, gate.wait, args.prewarm_ms)
+            except BaseException as exc:  # a dead thread must not leave the others at the barrier
+                errors.append(exc)
+                gate.abort()
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(ndev)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        torch.cuda.set_device(0)
+        main_run = runners[0]
+        steps, warm, launches = results[0][0], results[0][1], results[0][4]
+        wall, kern_ms = max(r[2] for r in results), max(r[3] for r in results)
+        world = ndev  # whole-job aggregate below
+    else:
+        main_run = Runner(args, args.mode, fir, dev, local_rank, world, rank)
+        steps, warm, wall, kern_ms, launches = main_run.measure(args.steps, args.warmup, barrier, args.prewarm_ms)
+    dist_info = {}
+    if barrier is not None:
         t = torch.tensor([wall, kern_ms], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         wall, kern_ms = float(t[0]), float(t[1])
+        # what the collective layer saw: the world size as torch.distributed reports it, and a 64-bit checksum of the
+        # spectrum every rank ended up with (all_gather): the broadcast is the path's only exchange step
+        import hashlib
+        mine = int.from_bytes(hashlib.blake2b(np.ascontiguousarray(main_run.bank.spectrum).tobytes(), digest_size=8).digest(), "little", signed=True)
+        tl = torch.tensor([mine], device=dev if backend == "nccl" else "cpu", dtype=torch.int64)
+        gathered = [torch.zeros_like(tl) for _ in range(tdist.get_world_size())]
+        tdist.all_gather(gathered, tl)
+        sums = [int(g[0]) for g in gathered]
+        dist_info = {"ranks_seen": tdist.get_world_size(), "backend": tdist.get_backend(),
+                     "spectrum_checksum": {"blake2b64_rank0": f"{sums[0] & 0xFFFFFFFFFFFFFFFF:016x}", "equal_on_all_ranks": len(set(sums)) == 1}}
+        carrier = f"torch.distributed broadcast ({tdist.get_backend()}) -> " + ("adsp_set_spectrum_device" if backend == "nccl" else "adsp_set_spectrum")
     sps, cps = main_run.samples_per_step, main_run.cps
     eng_desc = {"fft_size": main_run.eng.geometry.fft_size, "real": main_run.eng.real_spectrum,
                 "kept": N if args.mode == "stream" else main_run.eng.block_outputs, "taps": len(fir.taps)}
@@ -402,6 +486,37 @@ def main():
         except Exception as exc:
             latency = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
+    # BASELINE.json's own 8-GPU configurations, per-GPU shapes, after the headline (N > 1 only, so that the N = 1 line of
+    # a scaling run is the BENCH line): configs[3] HighCut(8000) on 8192 channels x 4096 per GPU, configs[4] the fused
+    # LowCut -> EQ3 -> HighCut chain @ 96 kHz on 4096 channels x 8192 per GPU.  Same step definition, same timing rules.
+    extra_configs = None
+    if barrier is not None and world > 1 and args.mode == "batch" and args.io == "f32" and args.effect == "none":
+        extra_configs = {}
+        try:
+            del main_run.ins, main_run.outs
+            torch.cuda.empty_cache()
+        except AttributeError:
+            pass
+        for key, argv in (("config4_highcut_8192ch_x_4096", ["--filter", "highcut", "--channels", "8192", "--chunk", "4096", "--fs", "44100"]),
+                          ("config5_chain_4096ch_x_8192_96k", ["--filter", "chain", "--channels", "4096", "--chunk", "8192", "--fs", "96000"])):
+            try:
+                ax = parse(argv)
+                rx = Runner(ax, "batch", make_fir(ax), dev, local_rank, world, rank)
+                x_steps, _, x_wall, x_kern, x_launches = rx.measure(max(2, min(args.steps, 8)), 2, barrier, min(args.prewarm_ms, 150.0))
+                t = torch.tensor([x_wall, x_kern], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+                tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+                x_wall, x_kern = float(t[0]), float(t[1])
+                per = x_kern / 1e3 / x_launches
+                extra_configs[key] = {"value": round(rx.samples_per_step * world * x_steps / x_wall / 1e6, 1), "unit": "Msamples/s", "n_gpus": world,
+                                      "steps": x_steps, "ms_per_step": round(x_wall * 1e3 / x_steps, 4),
+                                      "workload": f"{FILTER_NAMES[ax.filter]} @ {ax.fs} Hz, {ax.channels} channels x {ax.chunk}-sample chunks per GPU, "
+                                                  f"{rx.cps} chunks per step, {rx.eng.block_outputs} of {rx.eng.geometry.fft_size} samples kept per transform",
+                                      "roofline_frac": round(ALG_BYTES_PER_SAMPLE * rx.samples_per_step / per / 1e9 / HBM_PEAK_GBS, 4),
+                                      "avg_launch_us": round(per * 1e6, 2)}
+                del rx
+                torch.cuda.empty_cache()
+            except Exception as exc:
+                extra_configs[key] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     if rank == 0:
         value = sps * world * steps / wall / 1e6
         per_launch_s = kern_ms / 1e3 / launches
@@ -414,7 +529,11 @@ def main():
             try:
                 key = f"{args.filter}_{C}x{N}_{mode_key}" + ("" if args.io == "f32" else "_s16")
                 rec = json.load(open(tf)).get(key)
-                if rec:  # measured per launch at rec["steps_per_launch"] chunks; scale by the chunk count (traffic is linear in it)
+                if rec and rec.get("kernel_sha16") != kernel_sha16():
+                    # the counters were collected on a different build of the kernel: stale, so not reported
+                    traffic_src = (f"null: {rec.get('source')} was measured on kernel sources {rec.get('kernel_sha16', 'unstamped')}, "
+                                   f"this run is {kernel_sha16()} (re-run tools/profile_gpu.sh + tools/update_traffic.py)")
+                elif rec:  # measured per launch at rec["steps_per_launch"] chunks; scale by the chunk count (traffic is linear in it)
                     traffic = int(rec["hbm_bytes_per_launch"] * (cps / rec.get("steps_per_launch", cps)))
                     traffic_src = rec.get("source")
             except Exception:
@@ -447,6 +566,13 @@ def main():
                          "launches": launches, "algorithmic_bytes_per_launch": int(alg_bytes * samples_per_launch),
                          "traffic_source": traffic_src},
         }
+        line.update(dist_info)
+        if carrier:
+            line["spectrum_carrier"] = carrier
+        if getattr(args, "small", False):
+            line["small"] = True  # ADSP_BENCH_SMALL test hook: not the BASELINE shape
+        if extra_configs:
+            line["configs"] = extra_configs
         if extra_stream:
             line["stream"] = extra_stream
         if latency:

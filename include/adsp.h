@@ -41,7 +41,7 @@ extern "C" {
 #define ADSP_API
 #endif
 
-#define ADSP_ABI_VERSION 5
+#define ADSP_ABI_VERSION 6
 #define ADSP_MAX_HISTORY 8
 
 typedef enum adsp_status {
@@ -126,8 +126,24 @@ ADSP_API int adsp_set_spectrum(adsp_engine* engine, const float* spectrum_interl
 ADSP_API int adsp_set_spectrum_async(adsp_engine* engine, const float* spectrum_interleaved, int n_bins, void* stream);
 
 /* Same, from device memory (e.g. after an RCCL broadcast enqueued on `stream`): waits for `stream` only - the tables are
- * float64 host arithmetic, so the spectrum makes one trip to the host - then updates them stream-ordered as above. */
+ * float64 host arithmetic, so the spectrum makes one trip to the host - then updates them stream-ordered as above.
+ * Both stream-ordered updates rewrite the tables in place: NO launch of this engine may be in flight on any OTHER
+ * stream while they run (it would see half-old, half-new tables) - join such streams into `stream` first.
+ * Every adsp_set_spectrum* call forgets the kernel-reach hint (it described the previous kernel). */
 ADSP_API int adsp_set_spectrum_device(adsp_engine* engine, const float* d_spectrum_interleaved, int n_bins, void* stream);
+
+/* The one collective of the multi-GPU path: every engine of `engines[0..n)` - ONE engine per GPU, all
+ * in this process, all with the geometry of engines[root] - takes over the filter of engines[root].  The root's
+ * spectrum goes to its device, an RCCL broadcast (ncclBroadcast inside ncclGroupStart/End, one communicator per device
+ * from ncclCommInitAll: a single process needs no rendezvous) carries it over xGMI, and every engine - the root
+ * included - rebuilds its tables from what the collective left in ITS memory, so all n filters are bit-identical; the
+ * kernel-reach hint travels with it.  librccl.so is opened on first use (an RCCL already in the process wins, then
+ * $ADSP_RCCL_LIB, then the loader path); nothing else in this library needs it.  Set-up path: each device is drained.
+ * Channels never interact (each reference device is private state, Example2.py:13-21), so this is the only collective;
+ * a one-process-per-GPU host (torchrun) uses its own RCCL and adsp_set_spectrum_device instead. */
+ADSP_API int adsp_bcast_spectrum(adsp_engine* const* engines, int n, int root);
+/* Version code of the RCCL that adsp_bcast_spectrum uses (ncclGetVersion); ADSP_ERR_STATE when none can be opened. */
+ADSP_API int adsp_rccl_version(int* version);
 
 /* 1 when the spectrum last set is real (every imaginary part exactly 0 - a symmetric kernel centred on circular index
  * 0): the kernel then runs its cheaper spectrum stage.  0 otherwise. */
@@ -197,12 +213,23 @@ ADSP_API int adsp_apply_device(adsp_engine* engine, const void* d_in, void* d_ou
  * filters it.  No state copy, 1.25-1.75 N reads + N writes per channel per step.
  * Consecutive steps are independent kernels (step k reads ring slots k-history .. k and writes its own output):
  * issuing step k's producer + adsp_apply_ring on stream k % 2 of TWO streams lets the next launch fill the CUs the
- * previous one is draining (+8 % at 4096 ch x 4096, +22 % at 4096 ch x 512 measured).  That pattern needs no extra
- * synchronisation when the ring has >= history_chunks + 2 slots (the default 2 * history_chunks qualifies): the slot the
- * producer of step k overwrites was last read by step k - 2, which ran on the same stream.  With the minimum of
- * history_chunks + 1 slots the producer of step k must wait for step k - 1's kernel (the other stream). */
+ * previous one is draining.  The steps still depend on each other THROUGH THE RING, and the library orders them:
+ *   - step k reads the slots of steps k-1 .. k-history, filled by producers on other streams: adsp_apply_ring makes its
+ *     stream wait for an event recorded when each of those steps was submitted (their producers were complete);
+ *   - the producer of step k overwrites the slot of step k - ring_slots, which the kernels of steps k - ring_slots ..
+ *     k - ring_slots + history have read: adsp_ring_acquire_stream makes the producer's stream wait for those kernels.
+ * Nothing is recorded while every step arrives on one stream; the first step on a different stream joins the old stream
+ * once, and from then on each step costs two event records and up to history_chunks + 1 stream waits.  Producers must be
+ * enqueued on the stream given to adsp_ring_acquire_stream; plain adsp_ring_acquire knows no stream and, once several
+ * streams are in use, blocks the HOST until the slot's last readers have finished.  More slots than history_chunks + 1
+ * let a producer run further ahead of the kernels; correctness does not depend on the count. */
 ADSP_API int adsp_ring_acquire(adsp_engine* engine, void** d_slot);
+ADSP_API int adsp_ring_acquire_stream(adsp_engine* engine, void** d_slot, void* stream);
 ADSP_API int adsp_apply_ring(adsp_engine* engine, void* d_out, void* stream);
+/* Drain the device and forget the per-step ordering events.  Needed around hipGraph capture of ring steps: events
+ * recorded inside a capture must not be waited on outside it (and vice versa), so call this before the capture begins
+ * and again after it ends.  adsp_reset / adsp_get_state do the same as a side effect. */
+ADSP_API int adsp_ring_reset_order(adsp_engine* engine);
 
 /* Test hooks: the engine's history as [history_chunks][C][N] host floats, oldest first
  * (the reference's float32_array_input_3/_2). */

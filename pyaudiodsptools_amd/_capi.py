@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADSP_LIB") or os.path.join(_HERE, "libadsp.so")  # ADSP_LIB: tuning builds only
 
-ADSP_ABI_VERSION = 5
+ADSP_ABI_VERSION = 6
 ADSP_MAX_HISTORY = 8
 ADSP_FORMAT_F32, ADSP_FORMAT_S16 = 0, 1
 EFFECT_NONE, EFFECT_VOLUME, EFFECT_SOFT_CLIPPER, EFFECT_HARD_DISTORTION, EFFECT_SATURATOR, EFFECT_TREMOLO = 0, 1, 2, 3, 4, 5
@@ -106,6 +106,10 @@ SIGNATURES = {
     "adsp_apply_host": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "adsp_apply_device": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "adsp_ring_acquire": (ctypes.c_int, [_engine_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "adsp_ring_acquire_stream": (ctypes.c_int, [_engine_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
+    "adsp_ring_reset_order": (ctypes.c_int, [_engine_p]),
+    "adsp_bcast_spectrum": (ctypes.c_int, [ctypes.POINTER(_engine_p), ctypes.c_int, ctypes.c_int]),
+    "adsp_rccl_version": (ctypes.c_int, [_c_int_p]),
     "adsp_apply_ring": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_void_p]),
     "adsp_get_state": (ctypes.c_int, [_engine_p, ctypes.c_void_p]),
     "adsp_set_state": (ctypes.c_int, [_engine_p, ctypes.c_void_p]),
@@ -133,6 +137,11 @@ def load():
     # tensors, streams and this library share one device context.  torch is optional.
     try:
         import torch  # noqa: F401
+        # ... and one RCCL: adsp_bcast_spectrum opens librccl.so on first use; point it at the copy torch bundles (built
+        # against the HIP runtime that is now loaded) unless the caller chose one
+        rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(rccl):
+            os.environ.setdefault("ADSP_RCCL_LIB", rccl)
     except ImportError:
         pass
     lib = ctypes.CDLL(LIB_PATH)

@@ -17,6 +17,11 @@
 #include "capi_common.hpp"
 #include "plan_table.hpp"
 
+namespace adsp {  // adsp_rccl.hip
+int rccl_broadcast(float* const* d_buf, const int* devs, const hipStream_t* streams, int n, size_t count, int root);
+int rccl_version(int* version);
+}  // namespace adsp
+
 // standalone elementwise form of the fused output effects (fftconv_kernel.hpp::epilogue_value): out[i] = effect(in[i]);
 // the tremolo multiplies by its periodic LFO table, element 0 at table index `phase`
 __global__ void adsp_pointwise_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n, int op, float p0,
@@ -241,6 +246,8 @@ struct adsp_engine {
     char* zeros;   // 4*chunk_size zero bytes
     bool have_spectrum;
     bool real_spec;  // every Im H == 0: the kernel takes the 3-real-constants-per-pair path
+    std::vector<float> host_spec;  // the spectrum last set, interleaved (adsp_bcast_spectrum sends the root's)
+    float* d_spec;                 // 2 (M + 1) floats on the device: the buffer the RCCL broadcast runs on (lazily allocated)
     // stream-ordered table updates (adsp_set_spectrum_async): two pinned staging buffers, reused alternately
     char* pin_tab[2];
     size_t pin_tab_bytes;
@@ -263,6 +270,19 @@ struct adsp_engine {
     hipEvent_t ev_kernel;   // recorded right after the kernel when want_kernel_event is set
     bool want_kernel_event;
     bool timing;
+    // zero-copy ring steps issued on more than one stream (adsp_apply_ring): per-step events order a step after the
+    // producers of the history slots it reads (RAW) and a producer after the last readers of the slot it overwrites (WAR)
+    struct RingStep {
+        long long step = -1;
+        hipStream_t stream = nullptr;
+        hipEvent_t in = nullptr, out = nullptr;  // recorded just before / just after the step's kernel
+    };
+    std::vector<RingStep> ring_steps;
+    long long step_no;        // index of the next zero-copy step
+    bool multi_stream;        // a stream switch has been seen: events are recorded from then on
+    bool have_last_stream;
+    hipStream_t last_stream;
+    hipEvent_t ev_join;       // everything enqueued on the old stream when the first switch was seen
     hipStream_t copy_stream;  // ring update of multi-step launches runs beside the kernel
     hipEvent_t ev_in_ready, ev_copy_done;
     bool copy_pending;
@@ -301,6 +321,7 @@ int upload_pairs(adsp_engine* e, const float* H, hipStream_t stream, bool async 
     for (int k = 0; k <= M && real_spec; ++k) real_spec = H[2 * k + 1] == 0.0f;
     if (getenv("ADSP_FORCE_COMPLEX")) real_spec = false;  // tuning: A/B the two spectrum stages on the same filter
     e->real_spec = real_spec;
+    if (e->host_spec.data() != H) e->host_spec.assign(H, H + 2 * (size_t)(M + 1));
     // float4 layout [u][h][3][T]: (wc,g1) of pair 2h, (g2 of 2h, wc of 2h+1), (g1,g2) of 2h+1
     std::vector<float4> tab((size_t)PU * (npairs / 2) * 3 * T, make_float4(0.f, 0.f, 0.f, 0.f));
     if (real_spec) {
@@ -547,6 +568,7 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     e->zeros = nullptr;
     e->have_spectrum = false;
     e->real_spec = false;
+    e->d_spec = nullptr;
     e->kernel_reach = -1;
     e->pin_tab[0] = e->pin_tab[1] = nullptr;
     e->pin_tab_bytes = 0;
@@ -562,6 +584,10 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     e->ev_pin[0] = e->ev_pin[1] = e->ev_kernel = nullptr;
     e->want_kernel_event = false;
     e->timing = false;
+    e->step_no = 0;
+    e->multi_stream = e->have_last_stream = false;
+    e->last_stream = nullptr;
+    e->ev_join = nullptr;
     e->copy_stream = nullptr;
     e->ev_in_ready = e->ev_copy_done = nullptr;
     e->copy_pending = false;
@@ -604,6 +630,7 @@ int adsp_destroy(adsp_engine* e) {
     if (e->pair) (void)hipFree(e->pair);
     if (e->pair0) (void)hipFree(e->pair0);
     if (e->zeros) (void)hipFree(e->zeros);
+    if (e->d_spec) (void)hipFree(e->d_spec);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->ev_in_ready) (void)hipEventDestroy(e->ev_in_ready);
     if (e->ev_copy_done) (void)hipEventDestroy(e->ev_copy_done);
@@ -615,6 +642,11 @@ int adsp_destroy(adsp_engine* e) {
         if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : {e->ev_pin[0], e->ev_pin[1], e->ev_kernel})
         if (ev) (void)hipEventDestroy(ev);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    for (auto& st : e->ring_steps) {
+        if (st.in) (void)hipEventDestroy(st.in);
+        if (st.out) (void)hipEventDestroy(st.out);
+    }
     for (auto& v : {&e->timed, &e->free_ev})
         for (auto& p : *v) {
             (void)hipEventDestroy(p.first);
@@ -630,6 +662,7 @@ int adsp_set_spectrum(adsp_engine* e, const float* spectrum, int n_bins) {
     int rc = set_device(e);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());  // the tables may still be in use by queued launches
+    e->kernel_reach = -1;  // the hint described the previous kernel
     return upload_pairs(e, spectrum, nullptr);
 }
 
@@ -638,6 +671,7 @@ int adsp_set_spectrum_async(adsp_engine* e, const float* spectrum, int n_bins, v
     if (n_bins != e->M + 1) return fail(ADSP_ERR_ARG, "n_bins %d != fft_size/2+1 = %d", n_bins, e->M + 1);
     int rc = set_device(e);
     if (rc) return rc;
+    e->kernel_reach = -1;
     return upload_pairs(e, spectrum, (hipStream_t)stream, true);
 }
 
@@ -651,7 +685,68 @@ int adsp_set_spectrum_device(adsp_engine* e, const float* d_spectrum, int n_bins
     std::vector<float> host((size_t)2 * n_bins);
     HIP_TRY(hipMemcpyAsync(host.data(), d_spectrum, host.size() * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    e->kernel_reach = -1;
     return upload_pairs(e, host.data(), (hipStream_t)stream, true);
+}
+
+// The one collective of the multi-GPU path: every engine takes over the ROOT engine's filter.  One process, n devices.
+int adsp_bcast_spectrum(adsp_engine* const* engines, int n, int root) {
+    if (!engines || n < 1) return fail(ADSP_ERR_ARG, "need at least one engine");
+    if (root < 0 || root >= n) return fail(ADSP_ERR_ARG, "root %d out of range 0..%d", root, n - 1);
+    for (int i = 0; i < n; ++i) {
+        if (!engines[i]) return fail(ADSP_ERR_ARG, "engine %d is NULL", i);
+        for (int j = 0; j < i; ++j)
+            if (engines[j] == engines[i] || engines[j]->cfg.device_id == engines[i]->cfg.device_id)
+                return fail(ADSP_ERR_ARG, "engines %d and %d share device %d: one engine per GPU (RCCL ranks are devices)", j, i,
+                            engines[i]->cfg.device_id);
+    }
+    const adsp_engine* r = engines[root];
+    if (!r->have_spectrum) return fail(ADSP_ERR_STATE, "the root engine has no spectrum yet (adsp_set_spectrum)");
+    for (int i = 0; i < n; ++i) {
+        // a spectrum only means something together with the window geometry it was designed for
+        const adsp_config &a = engines[i]->cfg, &b = r->cfg;
+        if (a.chunk_size != b.chunk_size || a.fft_size != b.fft_size || a.history_chunks != b.history_chunks ||
+            a.lookback != b.lookback || a.out_offset != b.out_offset || a.sample_format != b.sample_format)
+            return fail(ADSP_ERR_ARG, "engine %d has a different geometry than the root engine (chunk %d/%d, fft %d/%d, lookback %d/%d, "
+                        "out_offset %d/%d)", i, a.chunk_size, b.chunk_size, a.fft_size, b.fft_size, a.lookback, b.lookback, a.out_offset, b.out_offset);
+    }
+    const size_t count = 2 * (size_t)(r->M + 1);
+    std::vector<float*> bufs(n);
+    std::vector<int> devs(n);
+    std::vector<hipStream_t> streams(n);
+    for (int i = 0; i < n; ++i) {
+        adsp_engine* e = engines[i];
+        int rc = set_device(e);
+        if (rc) return rc;
+        if (!e->d_spec) HIP_TRY(hipMalloc(&e->d_spec, count * sizeof(float)));
+        bufs[i] = e->d_spec;
+        devs[i] = e->cfg.device_id;
+        streams[i] = e->copy_stream;  // the engine's own side stream: nothing of the caller's is ordered behind the collective
+    }
+    {
+        adsp_engine* e = engines[root];
+        int rc = set_device(e);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(e->d_spec, e->host_spec.data(), count * sizeof(float), hipMemcpyHostToDevice, e->copy_stream));
+    }
+    int rc = adsp::rccl_broadcast(bufs.data(), devs.data(), streams.data(), n, count, root);
+    if (rc) return rc;
+    const int reach = r->kernel_reach;
+    for (int i = 0; i < n; ++i) {
+        // every engine, the root included, rebuilds its tables from what the collective left in ITS memory
+        adsp_engine* e = engines[i];
+        if ((rc = set_device(e))) return rc;
+        HIP_TRY(hipDeviceSynchronize());  // set-up path: the tables may still be in use by queued launches
+        if ((rc = adsp_set_spectrum_device(e, e->d_spec, r->M + 1, e->copy_stream))) return rc;
+        HIP_TRY(hipStreamSynchronize(e->copy_stream));
+        e->kernel_reach = reach;  // same kernel, same reach
+    }
+    return ADSP_OK;
+}
+
+int adsp_rccl_version(int* version) {
+    if (!version) return fail(ADSP_ERR_ARG, "version is NULL");
+    return adsp::rccl_version(version);
 }
 
 int adsp_spectrum_is_real(const adsp_engine* e, int* is_real) {
@@ -863,12 +958,64 @@ int adsp_set_accumulate(adsp_engine* e, int mode) {
     return ADSP_OK;
 }
 
+namespace {
+// ---- stream ordering of zero-copy ring steps ------------------------------------------------------------------
+// Step k reads ring slots k - history .. k (written by the producers of those steps) and the producer of step k
+// overwrites the slot of step k - ring_slots, which steps k - ring_slots .. k - ring_slots + history have read.  On ONE
+// stream the stream orders all of it and nothing is recorded.  The first time a step arrives on a different stream the
+// new stream joins the old one once (ev_join); from then on every step records an event before and after its kernel and
+// a step / producer on stream s waits for exactly the events of the conflicting steps that ran on other streams.
+void ring_forget_steps(adsp_engine* e) {  // after a device-wide synchronisation: nothing is in flight
+    for (auto& st : e->ring_steps) st.step = -1;
+    e->multi_stream = false;
+    e->have_last_stream = false;
+}
+
+int ring_enter_multi_stream(adsp_engine* e, hipStream_t stream) {
+    if (!e->ev_join) HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(e->ev_join, e->last_stream));
+    HIP_TRY(hipStreamWaitEvent(stream, e->ev_join, 0));
+    if (e->ring_steps.empty()) e->ring_steps.resize((size_t)e->cfg.ring_slots + e->cfg.history_chunks + 2);
+    for (auto& st : e->ring_steps) st.step = -1;
+    e->multi_stream = true;
+    return ADSP_OK;
+}
+
+// make `stream` wait for step `k`'s event (`out`: its kernel has finished; otherwise: its input was complete)
+int ring_wait_step(adsp_engine* e, long long k, hipStream_t stream, bool out) {
+    if (k < 0) return ADSP_OK;
+    const auto& st = e->ring_steps[(size_t)(k % (long long)e->ring_steps.size())];
+    if (st.step != k) {  // issued before the first stream switch: covered by the join event
+        HIP_TRY(hipStreamWaitEvent(stream, e->ev_join, 0));
+        return ADSP_OK;
+    }
+    if (st.stream != stream) HIP_TRY(hipStreamWaitEvent(stream, out ? st.out : st.in, 0));
+    return ADSP_OK;
+}
+
+// the producer about to fill the slot of step k on `stream` must come after the kernels that read its old contents
+int ring_order_producer(adsp_engine* e, hipStream_t stream) {
+    if (e->have_last_stream && !e->multi_stream && stream != e->last_stream) {
+        int rc = ring_enter_multi_stream(e, stream);
+        if (rc) return rc;
+    }
+    if (!e->multi_stream) return ADSP_OK;
+    const long long k = e->step_no, S = e->cfg.ring_slots;
+    for (int j = 0; j <= e->cfg.history_chunks; ++j) {
+        int rc = ring_wait_step(e, k - S + j, stream, true);
+        if (rc) return rc;
+    }
+    return ADSP_OK;
+}
+}  // namespace
+
 int adsp_reset(adsp_engine* e) {
     if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
     int rc = set_device(e);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     e->copy_pending = false;
+    ring_forget_steps(e);
     HIP_TRY(hipMemset(e->ring, 0, (size_t)e->cfg.ring_slots * e->plane_bytes()));
     e->ring_pos = e->cfg.ring_slots - 1;
     // a fused tremolo starts over as well (the reference pair would be filter.reset + a fresh CreateTremolo)
@@ -912,6 +1059,20 @@ int apply_device_run(adsp_engine* e, const void* d_in, void* d_out, int n_steps,
     // >= 2*history slots, so the copy can run on a side stream BESIDE the kernel: it waits for the caller's input
     // (event on `stream` before the launch) and the next launch on any stream waits for it (event after the copy).
     const bool side = (S >= 2 * e->cfg.history_chunks) && n_steps > 1;
+    if (e->multi_stream || (e->have_last_stream && e->last_stream != stream)) {
+        // zero-copy steps on other streams may still be in flight: this call joins them, then the step record starts over
+        if (!e->ev_join) HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+        for (auto& st : e->ring_steps)
+            if (st.step >= 0 && st.stream != stream) HIP_TRY(hipStreamWaitEvent(stream, st.out, 0));
+        if (e->have_last_stream && e->last_stream != stream) {
+            HIP_TRY(hipEventRecord(e->ev_join, e->last_stream));
+            HIP_TRY(hipStreamWaitEvent(stream, e->ev_join, 0));
+        }
+        for (auto& st : e->ring_steps) st.step = -1;
+        e->multi_stream = false;
+    }
+    e->have_last_stream = true;
+    e->last_stream = stream;
     if (e->copy_pending) {  // a previous side copy must have landed before this kernel reads the ring
         HIP_TRY(hipStreamWaitEvent(stream, e->ev_copy_done, 0));
         e->copy_pending = false;
@@ -941,7 +1102,35 @@ int adsp_ring_acquire(adsp_engine* e, void** d_slot) {
     if (!e || !d_slot) return fail(ADSP_ERR_ARG, "NULL argument");
     const int slot = (e->ring_pos + 1) % e->cfg.ring_slots;
     *d_slot = e->ring + (size_t)slot * e->plane_bytes();
+    if (e->multi_stream) {
+        // the caller did not say which stream the producer runs on: the HOST waits for the kernels that still read this slot
+        const long long k = e->step_no, S = e->cfg.ring_slots;
+        for (int j = 0; j <= e->cfg.history_chunks; ++j) {
+            const long long q = k - S + j;
+            if (q < 0) continue;
+            const auto& st = e->ring_steps[(size_t)(q % (long long)e->ring_steps.size())];
+            HIP_TRY(hipEventSynchronize(st.step == q ? st.out : e->ev_join));
+        }
+    }
     return ADSP_OK;
+}
+
+int adsp_ring_reset_order(adsp_engine* e) {
+    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    int rc = set_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    ring_forget_steps(e);
+    return ADSP_OK;
+}
+
+int adsp_ring_acquire_stream(adsp_engine* e, void** d_slot, void* stream_v) {
+    if (!e || !d_slot) return fail(ADSP_ERR_ARG, "NULL argument");
+    int rc = set_device(e);
+    if (rc) return rc;
+    const int slot = (e->ring_pos + 1) % e->cfg.ring_slots;
+    *d_slot = e->ring + (size_t)slot * e->plane_bytes();
+    return ring_order_producer(e, (hipStream_t)stream_v);
 }
 
 int adsp_apply_ring(adsp_engine* e, void* d_out, void* stream_v) {
@@ -954,9 +1143,32 @@ int adsp_apply_ring(adsp_engine* e, void* d_out, void* stream_v) {
         e->copy_pending = false;
     }
     const int slot = (e->ring_pos + 1) % e->cfg.ring_slots;
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (e->have_last_stream && !e->multi_stream && stream != e->last_stream && (rc = ring_enter_multi_stream(e, stream))) return rc;
+    adsp_engine::RingStep* rec = nullptr;
+    if (e->multi_stream) {
+        const long long k = e->step_no;
+        for (int j = 1; j <= e->cfg.history_chunks; ++j)  // the history this step reads was produced on other streams
+            if ((rc = ring_wait_step(e, k - j, stream, false))) return rc;
+        rec = &e->ring_steps[(size_t)(k % (long long)e->ring_steps.size())];
+        if (!rec->in) {
+            HIP_TRY(hipEventCreateWithFlags(&rec->in, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&rec->out, hipEventDisableTiming));
+        }
+        rec->step = -1;
+        HIP_TRY(hipEventRecord(rec->in, stream));  // this step's producer is complete
+    }
     if (e->epi_op == ADSP_EFFECT_TREMOLO) (void)tremolo_run(e, 1, &e->epi_phase);
-    if ((rc = launch(e, e->ring + (size_t)slot * e->plane_bytes(), d_out, 1, (hipStream_t)stream_v))) return rc;
+    if ((rc = launch(e, e->ring + (size_t)slot * e->plane_bytes(), d_out, 1, stream))) return rc;
+    if (rec) {
+        HIP_TRY(hipEventRecord(rec->out, stream));
+        rec->step = e->step_no;
+        rec->stream = stream;
+    }
     e->ring_pos = slot;
+    e->step_no += 1;
+    e->have_last_stream = true;
+    e->last_stream = stream;
     return ADSP_OK;
 }
 
@@ -1034,6 +1246,7 @@ int adsp_get_state(adsp_engine* e, void* host_history) {
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     e->copy_pending = false;
+    ring_forget_steps(e);
     const int S = e->cfg.ring_slots, nh = e->cfg.history_chunks;
     const size_t plane = e->plane_bytes();
     for (int h = 0; h < nh; ++h) {  // h = 0 oldest (time step -nh)

@@ -104,11 +104,14 @@ struct KernelArgs {
 // HALF_ = every LDS exchange runs in two rounds over HALF the buffer (elements < M/2, then the rest): 4 M bytes of LDS per
 // transform instead of 8 M, two more barriers per exchange - for the large transforms, whose LDS footprint is what keeps
 // a second or third workgroup off the CU.  MINW_ = waves per SIMD the register allocation must leave room for.
-template <int M_, int P_, int NP_, int A0, int A1, int A2, int A3, bool XL_ = false, bool HALF_ = false, int MINW_ = ADSP_MIN_WAVES>
+template <int M_, int P_, int NP_, int A0, int A1, int A2, int A3, bool XL_ = false, bool HALF_ = false, int MINW_ = ADSP_MIN_WAVES,
+          int MINW_AUX_ = MINW_>
 struct Plan {
     static constexpr int M = M_, P = P_, NP = NP_, T = M_ / P_;
     static constexpr bool XL = XL_, HALF = HALF_;
     static constexpr int MINW = MINW_;
+    // ... and what its int16 / fused-effect / generic-geometry siblings must leave room for (they need more registers)
+    static constexpr int minw(bool plain) { return plain ? MINW_ : MINW_AUX_; }
     static constexpr int LDS_ELEMS = HALF_ ? M_ / 2 : M_;
     static constexpr int fwd(int p) { return p == 0 ? A0 : p == 1 ? A1 : p == 2 ? A2 : A3; }
     static constexpr int inv(int p) { return fwd(NP_ - 1 - p); }
@@ -600,6 +603,11 @@ __device__ __forceinline__ void spectrum_stage(float (&xr)[PL::P], float (&xi)[P
     // bin k = j + (M/R)*r of a meets M - k = output R-1-r of b.  Tables: [u][...][T], the layouts of the NB = 2 case per pair.
 #pragma unroll
     for (int u = 0; u < NB / 2; ++u) {
+        // Three SEQUENTIAL ifs, not if / else-if / else: the self-paired test is lane-divergent, and LLVM's register
+        // liveness runs over the linearised control flow - with an else branch the inputs of the later branch stay live
+        // through the earlier one next to its outputs, which doubles the pressure of a stage that rewrites every
+        // register (the 64-point plan: 256 VGPRs + 120 B of scratch per lane with else branches, 230 VGPRs and none
+        // without).  Each region below rewrites the registers in place for the lanes it runs on.
         const bool self_paired = u == 0 && tid == 0;  // thread 0's pair 0: butterflies 0 and M/R/2 pair within themselves
         if (!self_paired && real_spec) {  // wave-uniform flag
             const float4* tab = pair + u * (R / 4) * 3 * T;
@@ -614,7 +622,8 @@ __device__ __forceinline__ void spectrum_stage(float (&xr)[PL::P], float (&xi)[P
                                  xi[NB * (R - 1 - r) + 2 * u + 1], c[3 * q], c[3 * q + 1], c[3 * q + 2]);
                 }
             }
-        } else if (!self_paired) {
+        }
+        if (!self_paired && !real_spec) {
             // two bin pairs share three 16-byte table loads
             const float4* tab = pair + u * (R / 2) * 3 * T;
 #pragma unroll
@@ -634,7 +643,8 @@ __device__ __forceinline__ void spectrum_stage(float (&xr)[PL::P], float (&xi)[P
                         xi[NB * (R - 1 - r1) + 2 * u + 1], make_float2(f1.z, f1.w), make_float2(f2.x, f2.y),
                         make_float2(f2.z, f2.w));
             }
-        } else {
+        }
+        if (self_paired) {
             // thread 0, pair 0 (u == 0 here): the self-paired butterflies j = 0 (registers NB*r) and j = M/R/2 (NB*r + 1).
             // entry 0: k = 0 (DC + Nyquist), entry 1: k = M/2, entries 2..: a-pairs r = 1..R/2-1
             // (k = D r with D (R-r), D = M/R), then b-pairs r = 0..R/2-1 (k = D/2 + D r with D/2 + D (R-1-r)).
@@ -1129,7 +1139,7 @@ __device__ __forceinline__ void transform_block(float (&xr)[PL::P], float (&xi)[
 // the kernel: one workgroup = CPB channels x one time block
 // ------------------------------------------------------------------------------------------
 template <class PL, int CPB, int FN, bool S16 = false, bool EPI = false>
-__global__ __launch_bounds__(PL::T* CPB, PL::MINW) void fftconv_kernel(const KernelArgs a) {
+__global__ __launch_bounds__(PL::T* CPB, PL::minw(!S16 && !EPI)) void fftconv_kernel(const KernelArgs a) {
     constexpr int M = PL::M, P = PL::P, T = PL::T;
     constexpr int N = 2 * M / FN;  // chunk size
     constexpr int LOGN = __builtin_ctz(N);
@@ -1263,7 +1273,7 @@ __device__ __forceinline__ void locate_chunk(int tau_biased, int N, float inv_n,
 }
 
 template <class PL, int CPB, bool S16 = false, bool EPI = false>
-__global__ __launch_bounds__(PL::T* CPB, PL::MINW) void fftconv_generic_kernel(const KernelArgs a) {
+__global__ __launch_bounds__(PL::T* CPB, PL::minw(false)) void fftconv_generic_kernel(const KernelArgs a) {
     constexpr int P = PL::P, T = PL::T;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2* lds = reinterpret_cast<float2*>(smem_raw);

@@ -68,7 +68,7 @@ constexpr PlanInfo make_plan() {
 //   M = 8192 : 32 points per thread, 168 VGPRs (3 waves per SIMD), 32 KiB of LDS -> THREE workgroups per CU  (+9 % over two)
 //   M = 16384: 64 points per thread, 4 waves per transform, 64 KiB of LDS        -> TWO workgroups per CU    (+13 % over one)
 #ifndef ADSP_PLAN_8192
-#define ADSP_PLAN_8192 Plan<8192, 32, 3, 32, 16, 16, 1, false, true, 3>
+#define ADSP_PLAN_8192 Plan<8192, 32, 3, 32, 16, 16, 1, false, true, 4, 3>
 #endif
 #ifndef ADSP_PLAN_16384
 #define ADSP_PLAN_16384 Plan<16384, 64, 3, 16, 32, 32, 1, false, true, 2>

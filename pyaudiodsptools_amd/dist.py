@@ -112,7 +112,7 @@ class ShardedFirBank:
             # (adsp_set_spectrum_device); the collective ran on torch's current stream, which is drained first
             import torch
             torch.cuda.current_stream(bdev).synchronize()
-            self.engine.upload_spectrum_device(self.spectrum_tensor, n_floats // 2)
+            self.engine.upload_spectrum_device(self.spectrum_tensor, n_floats // 2, reach=max(0, -geo.shift))
         else:
             # gloo / no process group: `self.spectrum` is the host copy taken after the collective completed
-            self.engine.upload_spectrum(self.spectrum)
+            self.engine.upload_spectrum(self.spectrum, reach=max(0, -geo.shift))

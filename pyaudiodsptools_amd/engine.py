@@ -15,13 +15,15 @@ _FORMATS = {"f32": (_capi.ADSP_FORMAT_F32, np.float32), "s16": (_capi.ADSP_FORMA
 
 
 def _ptr(x):
-    """Device/host address of a torch tensor, numpy array, or a raw integer address."""
+    """Device/host address of a torch tensor or numpy array, the handle of a torch stream, or a raw integer address / handle."""
     if x is None:
         return None
     if isinstance(x, int):
         return ctypes.c_void_p(x)
     if hasattr(x, "data_ptr"):  # torch tensor (plumbing only)
         return ctypes.c_void_p(x.data_ptr())
+    if hasattr(x, "cuda_stream"):  # torch.cuda.Stream: the raw hipStream_t
+        return ctypes.c_void_p(x.cuda_stream)
     if isinstance(x, np.ndarray):
         return ctypes.c_void_p(x.ctypes.data)
     raise TypeError(f"cannot take the address of {type(x)}")
@@ -84,9 +86,13 @@ class FirEngine:
         # taps at negative circular indices: lets the kernel skip the part of the window that feeds discarded outputs
         _capi.check(self._lib.adsp_set_kernel_reach(self._h, max(0, -geo.shift)))
 
-    def upload_spectrum(self, spectrum_f32):
+    def upload_spectrum(self, spectrum_f32, reach=None):
+        """Set a spectrum computed elsewhere (e.g. received by broadcast).  Every spectrum upload forgets the kernel-reach
+        hint; `reach` = taps at negative circular indices of THIS spectrum's kernel restores it (None: fetch whole windows)."""
         spec = np.ascontiguousarray(spectrum_f32, dtype=np.float32)
         _capi.check(self._lib.adsp_set_spectrum(self._h, _ptr(spec), spec.size // 2))
+        if reach is not None:
+            _capi.check(self._lib.adsp_set_kernel_reach(self._h, int(reach)))
 
     @property
     def real_spectrum(self):
@@ -95,8 +101,10 @@ class FirEngine:
         _capi.check(self._lib.adsp_spectrum_is_real(self._h, ctypes.byref(flag)))
         return bool(flag.value)
 
-    def upload_spectrum_device(self, d_spectrum, n_bins, stream=None):
+    def upload_spectrum_device(self, d_spectrum, n_bins, stream=None, reach=None):
         _capi.check(self._lib.adsp_set_spectrum_device(self._h, _ptr(d_spectrum), int(n_bins), _ptr(stream)))
+        if reach is not None:
+            _capi.check(self._lib.adsp_set_kernel_reach(self._h, int(reach)))
 
     def set_accumulate(self, mode=True):
         """0/False overwrite the output buffer; 1/True add to what it holds (later parts of a partitioned FIR, a mix
@@ -157,11 +165,20 @@ class FirEngine:
         """Asynchronous, device-resident [n_steps, C, N] float32 buffers (torch tensors or addresses)."""
         _capi.check(self._lib.adsp_apply_device(self._h, _ptr(d_in), _ptr(d_out), int(n_steps), _ptr(stream)))
 
-    def ring_acquire(self):
-        """Device address of the ring slot the producer must fill with the next [C, N] batch."""
+    def ring_acquire(self, stream=None):
+        """Device address of the ring slot the producer must fill with the next [C, N] batch.  Pass the stream the
+        producer runs on when steps are issued on several streams: it is ordered after the kernels that still read the
+        slot (adsp_ring_acquire_stream); without it the host blocks until they have finished."""
         p = ctypes.c_void_p(None)
-        _capi.check(self._lib.adsp_ring_acquire(self._h, ctypes.byref(p)))
+        if stream is None:
+            _capi.check(self._lib.adsp_ring_acquire(self._h, ctypes.byref(p)))
+        else:
+            _capi.check(self._lib.adsp_ring_acquire_stream(self._h, ctypes.byref(p), _ptr(stream)))
         return p.value
+
+    def ring_reset_order(self):
+        """Drain the device and forget the cross-stream ordering events of the ring (before and after hipGraph capture)."""
+        _capi.check(self._lib.adsp_ring_reset_order(self._h))
 
     def apply_ring(self, d_out, stream=None):
         _capi.check(self._lib.adsp_apply_ring(self._h, _ptr(d_out), _ptr(stream)))
@@ -177,6 +194,22 @@ class FirEngine:
 
     def synchronize(self, stream=None):
         _capi.check(self._lib.adsp_synchronize(self._h, _ptr(stream)))
+
+
+def broadcast_filter(engines, root=0):
+    """adsp_bcast_spectrum: every engine of the list (ONE per GPU, all in this process, same geometry) takes over the
+    filter of engines[root] through an RCCL broadcast inside libadsp - no torch, no rendezvous."""
+    lib = _capi.load()
+    arr = (ctypes.c_void_p * len(engines))(*[e._h for e in engines])
+    _capi.check(lib.adsp_bcast_spectrum(arr, len(engines), int(root)))
+    for e in engines:
+        e.fir, e.spectrum = engines[root].fir, engines[root].spectrum
+
+
+def rccl_version():
+    v = ctypes.c_int(0)
+    _capi.check(_capi.load().adsp_rccl_version(ctypes.byref(v)))
+    return v.value
 
 
 class ExactFirEngine:

@@ -34,7 +34,7 @@ class NumpyEngine:
         self.hist = np.zeros((channels, self.geometry.history_chunks * self.n))
         self.spec = None
 
-    def upload_spectrum(self, spectrum_f32):
+    def upload_spectrum(self, spectrum_f32, reach=None):
         self.spec = np.asarray(spectrum_f32, np.float32).view(np.complex64).astype(np.complex128)
 
     def apply_host(self, x):  # x [C, N]
