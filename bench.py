@@ -70,7 +70,7 @@ def parse(argv=None):
                          "transform tiles: 3 chunks = 2 blocks of 1.5 N kept samples for the cut filters)")
     ap.add_argument("--ring-slots", type=int, default=0, help="stream mode: input ring length (0 = history + 1, the smallest; "
                     "3 slots x 64 MiB stay inside the 256 MB Infinity Cache at the default shape)")
-    ap.add_argument("--fft-mult", type=int, default=0, help="force transform length = this multiple of the chunk (0 = smallest)")
+    ap.add_argument("--fft-mult", type=float, default=0, help="force transform length = this multiple of the chunk (1.5, 2 or 4; 0 = the library's choice)")
     ap.add_argument("--io", default="f32", choices=["f32", "s16"],
                     help="sample format of the resident batches: float32 (headline) or int16 PCM (fused WAV front end, 4 B/sample)")
     ap.add_argument("--effect", default="none", choices=["none", "softclip", "harddist", "saturator", "volume", "tremolo"],
@@ -354,6 +354,69 @@ def stream_figures(args, fir, dev, local_rank, world, rank, alg_bytes, channels=
     return out
 
 
+def resident_figures(args, fir, dev, alg_bytes, channels, chunk, launches=24, steps_per_launch=64, prewarm_ms=100.0):
+    """The same ring steps consumed by RESIDENT launches (adsp_apply_ring_resident): one launch covers `steps_per_launch`
+    steps, each step's workgroups wait for the producer's publication of that step (here: a producer stream that publishes
+    slots the set-up has already filled), so consecutive steps overlap inside one grid without a launch boundary."""
+    import torch
+    from pyaudiodsptools_amd import FirEngine, design
+    C, N = channels, chunk
+    geo = design.overlap_save_geometry(fir, args.fft_mult, "stream")
+    n = steps_per_launch
+    # 2 n + history slots: the producer fills the slots of launch L + 1 while launch L runs (it only ever waits for launch L - 1)
+    eng = FirEngine(fir, channels=C, device=dev.index, ring_slots=2 * n + geo.history_chunks, fft_mult=args.fft_mult,
+                    sample_format=args.io, optimize_for="stream")
+    dt = torch.int16 if args.io == "s16" else torch.float32
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4321)
+    scratch = torch.empty((C, N), device=dev, dtype=dt)
+    sptr = torch.cuda.current_stream(dev).cuda_stream
+    for _ in range(eng.ring_slots):  # set-up: every slot holds synthetic data
+        batch = (torch.randint(-16384, 16384, (C, N), device=dev, dtype=torch.int16, generator=gen) if args.io == "s16"
+                 else torch.empty((C, N), device=dev, dtype=torch.float32).uniform_(-1, 1, generator=gen))
+        eng.apply_device(batch, scratch, 1, sptr)
+    torch.cuda.synchronize(dev)
+    eng.ring_reset_order()
+    out = torch.empty((n, C, N), device=dev, dtype=dt)
+    prod = torch.cuda.Stream(device=dev)
+    cons = torch.cuda.Stream(device=dev)  # never the legacy default stream: it is implicitly ordered against `prod` (adsp.h)
+    sptr = cons.cuda_stream
+
+    def run(k_launches):
+        for _ in range(k_launches):
+            for _ in range(n):  # the (data-less) producer: takes the n slots in turn ...
+                eng.ring_produce_begin(prod)
+            eng.ring_produce_end(prod)  # ... and publishes them with one write of the sequence word
+            eng.apply_ring_resident(out, n, sptr)
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < prewarm_ms:
+        run(1)
+        torch.cuda.synchronize(dev)
+    run(2)
+    torch.cuda.synchronize(dev)
+    eng.enable_kernel_timing(True)
+    t0 = time.perf_counter()
+    run(launches)
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    k_ms, k_n = eng.kernel_time()
+    eng.enable_kernel_timing(False)
+    if eng.ring_resident_timed_out():
+        raise RuntimeError("a resident workgroup timed out waiting for its step")
+    chk = out.reshape(-1)[:: max(1, out.numel() // 65536)].float()
+    assert bool(torch.isfinite(chk).all()) and float(chk.abs().max()) > 0
+    steps = launches * n
+    per_step_kernel = k_ms / 1e3 / k_n / n
+    res = {"us_per_step": round(wall / steps * 1e6, 3), "kernel_us_per_step": round(per_step_kernel * 1e6, 3),
+           "value": round(C * N * steps / wall / 1e6, 1), "roofline_frac": round(alg_bytes * C * N / per_step_kernel / 1e9 / HBM_PEAK_GBS, 4),
+           "steps_per_launch": n, "launches": launches,
+           "note": f"adsp_apply_ring_resident: one launch consumes {n} ring steps, the workgroups of a step start when the producer stream "
+                   "has published it (sequence word in device memory); wall clock over whole launches incl. the publications"}
+    del eng, out
+    torch.cuda.empty_cache()
+    return res
+
+
 def numpy_api_latency(n=4096, reps=1500):
     """What a drop-in user of the reference API sees: dev.apply(numpy chunk) -> numpy chunk, one mono channel."""
     import pyaudiodsptools_amd as adsp
@@ -467,6 +530,10 @@ def main():
             del main_run.ins, main_run.outs
             torch.cuda.empty_cache()
             extra_stream = stream_figures(args, fir, dev, local_rank, world, rank, alg_bytes)
+            try:
+                extra_stream["resident"] = resident_figures(args, fir, dev, alg_bytes, C, N, launches=12, steps_per_launch=48)
+            except Exception as exc:
+                extra_stream["resident"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         except Exception as exc:
             extra_stream = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     if world == 1 and not args.no_latency and args.io == "f32" and args.effect == "none":
@@ -478,7 +545,11 @@ def main():
             a3 = parse(["--filter", "eq3", "--chunk", "512", "--fs", "44100", "--channels", "4096"] + (["--no-graph"] if args.no_graph else []))
             a3.prewarm_ms = min(args.prewarm_ms, 100.0)
             s3 = stream_figures(a3, make_fir(a3), dev, local_rank, world, rank, ALG_BYTES_PER_SAMPLE, steps=4096)
-            latency = {"config3_eq3_2048_stereo_pairs_x_512": {k: s3[k] for k in ("us_per_step", "avg_kernel_us", "value", "roofline_frac", "graph", "two_streams") if k in s3},
+            try:
+                s3["resident"] = resident_figures(a3, make_fir(a3), dev, ALG_BYTES_PER_SAMPLE, 4096, 512, launches=16, steps_per_launch=128)
+            except Exception as exc:
+                s3["resident"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            latency = {"config3_eq3_2048_stereo_pairs_x_512": {k: s3[k] for k in ("us_per_step", "avg_kernel_us", "value", "roofline_frac", "graph", "two_streams", "resident") if k in s3},
                        "numpy_api_apply_us_per_call": round(numpy_api_latency(), 2),
                        "note": "config 3 = CreateEQ3BandFFT(100,2,700,-4,8000,5) on 4096 mono channels (2048 stereo pairs) x 512 samples, one launch "
                                "per step (zero-copy ring); numpy API = CreateLowCutFilter(800).apply(float32[4096]) -> float32[4096], 1 channel, host "

@@ -226,6 +226,44 @@ ADSP_API int adsp_apply_device(adsp_engine* engine, const void* d_in, void* d_ou
 ADSP_API int adsp_ring_acquire(adsp_engine* engine, void** d_slot);
 ADSP_API int adsp_ring_acquire_stream(adsp_engine* engine, void** d_slot, void* stream);
 ADSP_API int adsp_apply_ring(adsp_engine* engine, void* d_out, void* stream);
+/* Resident ring launches: ONE launch consumes the next n_steps ring steps, and the workgroups of step k start as soon
+ * as the producer side has PUBLISHED that step - consecutive steps overlap inside one grid, with no launch boundary
+ * between them (per-step launches of small chunk batches spend a third of each step ramping up and draining: config 3,
+ * 4096 channels x 512 samples, EffectEQ3BandFFT.py:19).  The consumer may be launched before its input exists.
+ *   producer side, ONE stream, in step order:
+ *     adsp_ring_produce_begin(engine, &d_slot, stream)   slot of the next step to fill; orders `stream` after the
+ *                                                         launches that still read the slot's old contents
+ *     ... enqueue the copy / kernel that fills d_slot [C][N] on `stream` ...
+ *     adsp_ring_produce_end(engine, stream)              enqueues the publication of EVERY slot handed out since the last
+ *                                                         one: a 32-bit sequence word in device memory advances once
+ *                                                         everything before it on `stream` is done (a publication costs
+ *                                                         the host ~10 us: publish per step when steps arrive one by
+ *                                                         one, per batch when the producer fills several slots in a row)
+ *   consumer side:
+ *     adsp_apply_ring_resident(engine, d_out, n_steps, stream)   d_out [n_steps][C][N]; 1 <= n_steps <= ring_slots -
+ *                                                         history_chunks (size the ring for the run-ahead wanted).
+ *   Each workgroup polls the word for its step (thread 0, system-scope loads, s_sleep between polls), every wave then
+ *   executes an acquire fence before it loads the window.  A workgroup that has waited longer than the time-out
+ *   (default 250 ms, adsp_ring_resident_timeout) gives up WITHOUT writing its outputs and raises a flag that
+ *   adsp_ring_resident_status returns (and clears): a consumer without a producer cannot hang the GPU.  After a
+ *   time-out the stream state is undefined: adsp_reset.
+ *   Waiting workgroups HOLD their CU slots (the launch runs step-major, so only the steps next in line are resident).
+ *   LIMITATION (measured, tools/resident_probe.py, profiles/r3_resident.txt): a launch whose grid is larger than the GPU
+ *   holds at once (n_steps x workgroups per step > ~3000) and whose NEXT step is not yet published stops dispatching, and on
+ *   MI355X / ROCm 7.2 the producer stream's commands - the runtime's own write of the sequence word included - then do not
+ *   get through either: the launch ends by time-out.  Launch the consumer before its input only with grids the GPU can hold
+ *   (the -m gpu test: 20 workgroups per step); at full size publish first - the launch then never waits and runs at the
+ *   multi-step rate (config 3: 5.5-5.8 us per step against 8.0 for one launch per step).
+ *   Use explicitly created streams for both sides: work on the legacy default (NULL) stream is implicitly ordered against
+ *   every blocking stream, so a producer would wait for the very launch that waits for it.
+ *   Resident and per-step ring calls do not mix: adsp_ring_reset_order (a drain) switches between them.
+ *   Not available for the generic-geometry kernels and with a fused tremolo. */
+ADSP_API int adsp_ring_produce_begin(adsp_engine* engine, void** d_slot, void* stream);
+ADSP_API int adsp_ring_produce_end(adsp_engine* engine, void* stream);
+ADSP_API int adsp_apply_ring_resident(adsp_engine* engine, void* d_out, int n_steps, void* stream);
+ADSP_API int adsp_ring_resident_timeout(adsp_engine* engine, double milliseconds);
+ADSP_API int adsp_ring_resident_status(adsp_engine* engine, int* timed_out);
+
 /* Drain the device and forget the per-step ordering events.  Needed around hipGraph capture of ring steps: events
  * recorded inside a capture must not be waited on outside it (and vice versa), so call this before the capture begins
  * and again after it ends.  adsp_reset / adsp_get_state do the same as a side effect. */

@@ -108,6 +108,11 @@ SIGNATURES = {
     "adsp_ring_acquire": (ctypes.c_int, [_engine_p, ctypes.POINTER(ctypes.c_void_p)]),
     "adsp_ring_acquire_stream": (ctypes.c_int, [_engine_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
     "adsp_ring_reset_order": (ctypes.c_int, [_engine_p]),
+    "adsp_ring_produce_begin": (ctypes.c_int, [_engine_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
+    "adsp_ring_produce_end": (ctypes.c_int, [_engine_p, ctypes.c_void_p]),
+    "adsp_apply_ring_resident": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "adsp_ring_resident_timeout": (ctypes.c_int, [_engine_p, ctypes.c_double]),
+    "adsp_ring_resident_status": (ctypes.c_int, [_engine_p, _c_int_p]),
     "adsp_bcast_spectrum": (ctypes.c_int, [ctypes.POINTER(_engine_p), ctypes.c_int, ctypes.c_int]),
     "adsp_rccl_version": (ctypes.c_int, [_c_int_p]),
     "adsp_apply_ring": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_void_p]),

@@ -115,18 +115,18 @@ using adsp::fail;
 
 using adsp::PlanInfo;
 
-const PlanInfo* find_plan(int M, int FN, int fmt) {
+const PlanInfo* find_plan(int M, int FQ, int fmt) {
     int n = 0;
     if (fmt == ADSP_FORMAT_F32) {
         if (const char* v = getenv("ADSP_PLAN_VARIANT")) {
             const PlanInfo* var = adsp::variants_f32(&n);
             const int i = atoi(v);
-            if (i >= 0 && i < n && var[i].M == M && var[i].FN == FN) return &var[i];
+            if (i >= 0 && i < n && var[i].M == M && var[i].FQ == FQ) return &var[i];
         }
     }
     const PlanInfo* tab = fmt == ADSP_FORMAT_S16 ? adsp::plans_s16(&n) : adsp::plans_f32(&n);
     for (int i = 0; i < n; ++i)
-        if (tab[i].M == M && tab[i].FN == FN) return &tab[i];
+        if (tab[i].M == M && tab[i].FQ == FQ) return &tab[i];
     return nullptr;
 }
 
@@ -150,9 +150,12 @@ int ilog2(int v) {
 int check_geometry(int N, int F, int fmt, const PlanInfo** out, bool* generic) {
     if (fmt != ADSP_FORMAT_F32 && fmt != ADSP_FORMAT_S16) return fail(ADSP_ERR_ARG, "sample_format %d: need ADSP_FORMAT_F32 or ADSP_FORMAT_S16", fmt);
     if (N < 16 || N % 4) return fail(ADSP_ERR_ARG, "chunk_size %d: need a multiple of 4, >= 16", N);
-    if (!is_pow2(F) || F < 128 || F > 32768) return fail(ADSP_ERR_ARG, "fft_size %d: need a power of two in 128..32768", F);
-    const bool special = is_pow2(N) && N >= 64 && N <= 8192 && (F == 2 * N || F == 4 * N);
-    const PlanInfo* p = special ? find_plan(F / 2, F / N, fmt) : find_plan_any_fn(F / 2, fmt);
+    const bool three = F % 3 == 0 && is_pow2(F / 3);  // 3 * 2^k: the 1.5 N windows of the specialised kernels only
+    if (!(is_pow2(F) || three) || F < 128 || F > 32768)
+        return fail(ADSP_ERR_ARG, "fft_size %d: need a power of two in 128..32768 (or 1.5 x a power-of-two chunk that has a plan)", F);
+    const bool special = is_pow2(N) && N >= 64 && N <= 8192 && (F == 2 * N || F == 4 * N || 2 * F == 3 * N);
+    if (three && !special) return fail(ADSP_ERR_ARG, "fft_size %d = 3 * 2^k is only available as 1.5 x chunk_size", F);
+    const PlanInfo* p = special ? find_plan(F / 2, 4 * F / N, fmt) : find_plan_any_fn(F / 2, fmt);
     if (!p) return fail(ADSP_ERR_ARG, "no kernel plan for %d complex points", F / 2);
     if (out) *out = p;
     if (generic) *generic = !special;
@@ -283,6 +286,26 @@ struct adsp_engine {
     bool have_last_stream;
     hipStream_t last_stream;
     hipEvent_t ev_join;       // everything enqueued on the old stream when the first switch was seen
+    // resident ring launches (adsp_ring_produce_begin/_end, adsp_apply_ring_resident): the producer side publishes steps
+    // through a device sequence word, a consumer launch covers many steps and its workgroups wait for theirs
+    struct ResidentLaunch {
+        long long first = 0;
+        int n = 0;
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        hipStream_t waited_by = nullptr;  // the producer stream that already waits for `done` (one wait per launch, not per slot)
+        bool waited = false;
+    };
+    std::vector<ResidentLaunch> resident_launches;  // the most recent ones (ring order of producers against their readers)
+    size_t resident_next;
+    bool resident_mode;
+    unsigned* d_seq;          // [0] sequence word = number of steps published so far, [1] time-out flag; fine-grained device memory
+    unsigned pub_count;       // host copy of the sequence word once every enqueued publication has executed
+    int pub_pending;          // slots handed out by adsp_ring_produce_begin since the last publication
+    int lead;                 // steps published but not yet handed to a consumer launch (negative: consumers launched ahead)
+    bool seq_by_copy;         // hipStreamWriteValue32 is not available: publications are 4-byte copies from pinned memory
+    unsigned* pin_seq;        // pinned source values of such copies (kSeqPinned of them, reused round-robin)
+    unsigned long long resident_timeout_ticks;
     hipStream_t copy_stream;  // ring update of multi-step launches runs beside the kernel
     hipEvent_t ev_in_ready, ev_copy_done;
     bool copy_pending;
@@ -391,7 +414,7 @@ int upload_pairs(adsp_engine* e, const float* H, hipStream_t stream, bool async 
     return ADSP_OK;
 }
 
-int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream_t stream) {
+int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream_t stream, bool resident = false) {
     const adsp_config& c = e->cfg;
     // same transform; the twin kernel has the output effect / mix bus compiled in (the plain generic kernel can add)
     const bool twin = e->epi_op != 0 || e->accumulate == 2 || (e->accumulate == 1 && !e->generic);
@@ -408,7 +431,13 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
     a.ring_slots = c.ring_slots;
     a.C = c.n_channels;
     a.n_steps = n_steps;
-    a.V = (n_steps == 1 && !e->generic) ? c.chunk_size : e->block_outputs;
+    a.V = ((n_steps == 1 || resident) && !e->generic) ? c.chunk_size : e->block_outputs;
+    a.in_ring = resident ? 1 : 0;
+    a.step_tile = (resident && e->lead >= n_steps) ? 4 : 1;
+    a.seq = resident ? e->d_seq : nullptr;
+    a.seq_base = e->pub_count - (unsigned)e->lead;  // (wraps like the word itself)
+    a.seq_fail = resident ? e->d_seq + 1 : nullptr;
+    a.seq_timeout = e->resident_timeout_ticks;
     a.N = c.chunk_size;
     a.nh = c.history_chunks;
     a.inv_n = 1.0f / (float)c.chunk_size;
@@ -435,7 +464,7 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
     a.lookback = c.lookback;
     a.j0 = c.out_offset;
     a.ncg = (c.n_channels + pl.CPB - 1) / pl.CPB;
-    const long long grid = (long long)((a.ncg + 7) / 8) * 8 * a.nblk;
+    const long long grid = (long long)((a.ncg + 7) / 8) * 8 * (resident ? (a.nblk + 3) / 4 * 4 : a.nblk);  // resident: whole tiles of 4 steps
     if (grid > 0x7fffffffLL) return fail(ADSP_ERR_ARG, "launch too large (%lld workgroups)", grid);
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     if (e->timing) {
@@ -460,6 +489,10 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
+#define ADSP_NOT_RESIDENT(e)                                                                                              \
+    if ((e)->resident_mode)                                                                                                \
+        return fail(ADSP_ERR_STATE, "the ring is in resident mode (adsp_ring_produce_* / adsp_apply_ring_resident): call adsp_ring_reset_order first")
+
 extern "C" {
 
 int adsp_version(void) { return ADSP_ABI_VERSION; }
@@ -584,6 +617,15 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     e->ev_pin[0] = e->ev_pin[1] = e->ev_kernel = nullptr;
     e->want_kernel_event = false;
     e->timing = false;
+    e->resident_next = 0;
+    e->resident_mode = false;
+    e->d_seq = nullptr;
+    e->pub_count = 0;
+    e->pub_pending = 0;
+    e->lead = 0;
+    e->seq_by_copy = getenv("ADSP_SEQ_COPY") != nullptr;  // tuning: publish through 4-byte copies instead of hipStreamWriteValue32
+    e->pin_seq = nullptr;
+    e->resident_timeout_ticks = 25000000ull;  // 250 ms of the 100 MHz clock
     e->step_no = 0;
     e->multi_stream = e->have_last_stream = false;
     e->last_stream = nullptr;
@@ -643,6 +685,10 @@ int adsp_destroy(adsp_engine* e) {
     for (hipEvent_t ev : {e->ev_pin[0], e->ev_pin[1], e->ev_kernel})
         if (ev) (void)hipEventDestroy(ev);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    for (auto& rl : e->resident_launches)
+        if (rl.done) (void)hipEventDestroy(rl.done);
+    if (e->d_seq) (void)hipFree(e->d_seq);
+    if (e->pin_seq) (void)hipHostFree(e->pin_seq);
     for (auto& st : e->ring_steps) {
         if (st.in) (void)hipEventDestroy(st.in);
         if (st.out) (void)hipEventDestroy(st.out);
@@ -969,6 +1015,29 @@ void ring_forget_steps(adsp_engine* e) {  // after a device-wide synchronisation
     for (auto& st : e->ring_steps) st.step = -1;
     e->multi_stream = false;
     e->have_last_stream = false;
+    for (auto& rl : e->resident_launches) rl.n = 0;
+    e->resident_mode = false;
+}
+
+constexpr int kSeqPinned = 4096;
+
+int resident_prepare(adsp_engine* e) {
+    if (e->generic) return fail(ADSP_ERR_STATE, "resident ring launches need a specialised kernel (power-of-two chunk, F = 1.5 / 2 / 4 N)");
+    if (e->multi_stream) return fail(ADSP_ERR_STATE, "ring steps are in flight on several streams: call adsp_ring_reset_order before the resident calls");
+    if (!e->d_seq) {
+        void* p = nullptr;
+        if (hipExtMallocWithFlags(&p, 2 * sizeof(unsigned), hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(hipMalloc(&p, 2 * sizeof(unsigned)));
+        }
+        e->d_seq = static_cast<unsigned*>(p);
+        HIP_TRY(hipMemset(e->d_seq, 0, 2 * sizeof(unsigned)));
+        HIP_TRY(hipDeviceSynchronize());
+        e->pub_count = 0;
+        e->resident_launches.resize(8);
+    }
+    e->resident_mode = true;
+    return ADSP_OK;
 }
 
 int ring_enter_multi_stream(adsp_engine* e, hipStream_t stream) {
@@ -1016,6 +1085,8 @@ int adsp_reset(adsp_engine* e) {
     HIP_TRY(hipDeviceSynchronize());
     e->copy_pending = false;
     ring_forget_steps(e);
+    e->lead = 0;
+    e->pub_pending = 0;
     HIP_TRY(hipMemset(e->ring, 0, (size_t)e->cfg.ring_slots * e->plane_bytes()));
     e->ring_pos = e->cfg.ring_slots - 1;
     // a fused tremolo starts over as well (the reference pair would be filter.reset + a fresh CreateTremolo)
@@ -1033,6 +1104,7 @@ int adsp_apply_device(adsp_engine* e, const void* d_in, void* d_out, int n_steps
     if (!e || !d_in || !d_out) return fail(ADSP_ERR_ARG, "NULL argument");
     if (n_steps <= 0) return fail(ADSP_ERR_ARG, "n_steps must be positive");
     if (!e->have_spectrum) return fail(ADSP_ERR_STATE, "adsp_set_spectrum has not been called");
+    ADSP_NOT_RESIDENT(e);
     int rc = set_device(e);
     if (rc) return rc;
     if (e->epi_op != ADSP_EFFECT_TREMOLO) return apply_device_run(e, d_in, d_out, n_steps, stream_v);
@@ -1094,12 +1166,15 @@ int apply_device_run(adsp_engine* e, const void* d_in, void* d_out, int n_steps,
         e->copy_pending = true;  // a later call on a DIFFERENT stream must also wait for it
     }
     e->ring_pos = (e->ring_pos + cnt) % S;
+    e->step_no += n_steps;
+    e->lead = 0;
     return ADSP_OK;
 }
 }  // namespace
 
 int adsp_ring_acquire(adsp_engine* e, void** d_slot) {
     if (!e || !d_slot) return fail(ADSP_ERR_ARG, "NULL argument");
+    ADSP_NOT_RESIDENT(e);
     const int slot = (e->ring_pos + 1) % e->cfg.ring_slots;
     *d_slot = e->ring + (size_t)slot * e->plane_bytes();
     if (e->multi_stream) {
@@ -1121,11 +1196,13 @@ int adsp_ring_reset_order(adsp_engine* e) {
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     ring_forget_steps(e);
+    if (e->lead < 0) e->lead = 0;  // consumer launches that ran ahead have ended (served or timed out)
     return ADSP_OK;
 }
 
 int adsp_ring_acquire_stream(adsp_engine* e, void** d_slot, void* stream_v) {
     if (!e || !d_slot) return fail(ADSP_ERR_ARG, "NULL argument");
+    ADSP_NOT_RESIDENT(e);
     int rc = set_device(e);
     if (rc) return rc;
     const int slot = (e->ring_pos + 1) % e->cfg.ring_slots;
@@ -1136,6 +1213,7 @@ int adsp_ring_acquire_stream(adsp_engine* e, void** d_slot, void* stream_v) {
 int adsp_apply_ring(adsp_engine* e, void* d_out, void* stream_v) {
     if (!e || !d_out) return fail(ADSP_ERR_ARG, "NULL argument");
     if (!e->have_spectrum) return fail(ADSP_ERR_STATE, "adsp_set_spectrum has not been called");
+    ADSP_NOT_RESIDENT(e);
     int rc = set_device(e);
     if (rc) return rc;
     if (e->copy_pending) {
@@ -1167,8 +1245,115 @@ int adsp_apply_ring(adsp_engine* e, void* d_out, void* stream_v) {
     }
     e->ring_pos = slot;
     e->step_no += 1;
+    if (e->lead > 0) e->lead -= 1;  // a chunk published through adsp_ring_produce_* and consumed step by step
     e->have_last_stream = true;
     e->last_stream = stream;
+    return ADSP_OK;
+}
+
+// ---- resident ring launches -------------------------------------------------------------------------------------
+int adsp_ring_produce_begin(adsp_engine* e, void** d_slot, void* stream_v) {
+    if (!e || !d_slot) return fail(ADSP_ERR_ARG, "NULL argument");
+    int rc = set_device(e);
+    if (rc) return rc;
+    if ((rc = resident_prepare(e))) return rc;
+    const int S = e->cfg.ring_slots, h = e->cfg.history_chunks;
+    const int ahead = e->lead + e->pub_pending;  // steps handed to the producer and not yet handed to a consumer launch
+    if (ahead >= S - h) return fail(ADSP_ERR_STATE, "ring full: %d steps produced and not yet consumed (ring_slots %d - history %d)", ahead, S, h);
+    hipStream_t stream = (hipStream_t)stream_v;
+    const int slot = (((e->ring_pos + 1 + ahead) % S) + S) % S;
+    // the old contents of this slot are step q - S, read by steps q - S .. q - S + h: wait for the resident launches that hold them
+    const long long q = e->step_no + ahead;
+    for (auto& rl : e->resident_launches)
+        if (rl.n > 0 && rl.stream != stream && rl.first <= q - S + h && rl.first + rl.n > q - S && !(rl.waited && rl.waited_by == stream)) {
+            HIP_TRY(hipStreamWaitEvent(stream, rl.done, 0));
+            rl.waited = true;
+            rl.waited_by = stream;
+        }
+    *d_slot = e->ring + (size_t)slot * e->plane_bytes();
+    e->pub_pending += 1;
+    return ADSP_OK;
+}
+
+int adsp_ring_produce_end(adsp_engine* e, void* stream_v) {
+    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    if (!e->resident_mode || e->pub_pending < 1) return fail(ADSP_ERR_STATE, "adsp_ring_produce_end without adsp_ring_produce_begin");
+    int rc = set_device(e);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_v;
+    const unsigned value = e->pub_count + (unsigned)e->pub_pending;  // every slot handed out since the last publication
+    if (!e->seq_by_copy) {
+        const hipError_t werr = hipStreamWriteValue32(stream, e->d_seq, value, 0);
+        if (werr != hipSuccess) {
+            (void)hipGetLastError();
+            e->seq_by_copy = true;
+            if (getenv("ADSP_DEBUG")) fprintf(stderr, "libadsp: hipStreamWriteValue32 failed (%s): publications become 4-byte copies\n", hipGetErrorString(werr));
+        }
+    }
+    if (e->seq_by_copy) {
+        if (!e->pin_seq) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->pin_seq), kSeqPinned * sizeof(unsigned), hipHostMallocDefault));
+        unsigned* src = e->pin_seq + value % kSeqPinned;  // reused after kSeqPinned publications: far more than a ring holds
+        *src = value;
+        HIP_TRY(hipMemcpyAsync(e->d_seq, src, sizeof(unsigned), hipMemcpyHostToDevice, stream));
+    }
+    e->pub_count = value;
+    e->lead += e->pub_pending;
+    e->pub_pending = 0;
+    return ADSP_OK;
+}
+
+int adsp_apply_ring_resident(adsp_engine* e, void* d_out, int n_steps, void* stream_v) {
+    if (!e || !d_out) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (!e->have_spectrum) return fail(ADSP_ERR_STATE, "adsp_set_spectrum has not been called");
+    int rc = set_device(e);
+    if (rc) return rc;
+    if ((rc = resident_prepare(e))) return rc;
+    const int S = e->cfg.ring_slots, h = e->cfg.history_chunks;
+    if (n_steps < 1 || n_steps > S - h)
+        return fail(ADSP_ERR_ARG, "n_steps %d: a resident launch covers 1..ring_slots - history_chunks = %d steps (the slots its own steps do not read)", n_steps, S - h);
+    if (e->epi_op == ADSP_EFFECT_TREMOLO) return fail(ADSP_ERR_STATE, "a fused tremolo is not supported by resident launches");
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (e->copy_pending) {
+        HIP_TRY(hipStreamWaitEvent(stream, e->ev_copy_done, 0));
+        e->copy_pending = false;
+    }
+    hipStream_t run = stream;
+    if ((rc = launch(e, e->ring, d_out, n_steps, run, true))) return rc;
+    auto& rl = e->resident_launches[e->resident_next++ % e->resident_launches.size()];
+    if (!rl.done) HIP_TRY(hipEventCreateWithFlags(&rl.done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(rl.done, run));
+    rl.first = e->step_no;
+    rl.n = n_steps;
+    rl.stream = stream;
+    rl.waited = false;
+    e->ring_pos = (e->ring_pos + n_steps) % S;
+    e->step_no += n_steps;
+    e->lead -= n_steps;
+    e->have_last_stream = true;
+    e->last_stream = stream;
+    return ADSP_OK;
+}
+
+int adsp_ring_resident_timeout(adsp_engine* e, double milliseconds) {
+    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    if (!(milliseconds > 0.0) || milliseconds > 60000.0) return fail(ADSP_ERR_ARG, "time-out must be in (0, 60000] ms");
+    e->resident_timeout_ticks = (unsigned long long)(milliseconds * 1e5);  // 100 MHz
+    return ADSP_OK;
+}
+
+int adsp_ring_resident_status(adsp_engine* e, int* timed_out) {
+    if (!e || !timed_out) return fail(ADSP_ERR_ARG, "NULL argument");
+    *timed_out = 0;
+    if (!e->d_seq) return ADSP_OK;
+    int rc = set_device(e);
+    if (rc) return rc;
+    unsigned flag = 0;
+    HIP_TRY(hipMemcpy(&flag, e->d_seq + 1, sizeof flag, hipMemcpyDeviceToHost));
+    if (flag) {
+        const unsigned zero = 0;
+        HIP_TRY(hipMemcpy(e->d_seq + 1, &zero, sizeof zero, hipMemcpyHostToDevice));
+    }
+    *timed_out = flag ? 1 : 0;
     return ADSP_OK;
 }
 

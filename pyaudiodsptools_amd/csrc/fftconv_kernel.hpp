@@ -93,6 +93,14 @@ struct KernelArgs {
                            // outputs - a single-step launch of a zero-phase cut filter needs 1.5 N of its 2 N window
     int accumulate;        // 1: add the kept samples to what `out` holds (partitioned FIRs, mixing); 2: and clip the sum
                            // to [-1, 1] (MixSignals).  Plain kernels: generic geometry + mode 1 only; EPI kernels: all.
+    // resident ring launches (adsp_apply_ring_resident): the new chunks are ring slots too (`in` is unused) and block b may
+    // only start once the producer has PUBLISHED step b - the 32-bit sequence word has reached seq_base + b + 1
+    int in_ring;                   // chunks q >= 0 are ring slots (ring_pos + 1 + q) mod ring_slots
+    int step_tile;                 // 1 or 4: steps per tile of the step-major workgroup order
+    const unsigned* seq;           // device sequence word the producer side bumps after filling a slot (nullptr: no waiting)
+    unsigned seq_base;             // value of the word when every step before this launch had been published
+    unsigned* seq_fail;            // set to 1 by a workgroup that gave up waiting (its block's outputs are then not written)
+    unsigned long long seq_timeout;  // in ticks of the constant 100 MHz clock (wall_clock64)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -269,6 +277,55 @@ struct Dft {
     }
 };
 
+// DFT-3 (forward sign): W3 = -1/2 - i sqrt(3)/2
+__device__ __forceinline__ void dft3(float x0r, float x0i, float x1r, float x1i, float x2r, float x2i, float& y0r, float& y0i,
+                                     float& y1r, float& y1i, float& y2r, float& y2i) {
+    constexpr float kS = 0.86602540378443864676f;
+    const float tr = x1r + x2r, ti = x1i + x2i;
+    const float mr = x0r - 0.5f * tr, mi = x0i - 0.5f * ti;
+    const float sr = (x1r - x2r) * kS, si = (x1i - x2i) * kS;
+    y0r = x0r + tr;
+    y0i = x0i + ti;
+    y1r = mr + si;  // m - i s
+    y1i = mi - sr;
+    y2r = mr - si;  // m + i s
+    y2i = mi + sr;
+}
+
+// DFT-12 as a prime-factor (Good-Thomas) 3 x 4: input n = (4 n1 + 3 n2) mod 12, output k = (4 k1 + 9 k2) mod 12 - then
+// W12^(nk) = W3^(n1 k1) W4^(n2 k2), no twiddles between the two stages (96 real additions/multiplications).  The radix of
+// the 3 * 2^k-point transforms (F = 1.5 N windows: the minimal window of the reference's cut filters, EffectFFTFilter.py:22-25).
+template <>
+struct Dft<12> {
+    static __device__ __forceinline__ void run(const float (&xr)[12], const float (&xi)[12], float (&yr)[12], float (&yi)[12]) {
+        float ar[3][4], ai[3][4];  // [k1][n2]
+#pragma unroll
+        for (int n2 = 0; n2 < 4; ++n2) {
+            const int i0 = (3 * n2) % 12, i1 = (4 + 3 * n2) % 12, i2 = (8 + 3 * n2) % 12;
+            dft3(xr[i0], xi[i0], xr[i1], xi[i1], xr[i2], xi[i2], ar[0][n2], ai[0][n2], ar[1][n2], ai[1][n2], ar[2][n2], ai[2][n2]);
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < 3; ++k1) {
+            float br[4], bi[4];
+            Dft<4>::run(ar[k1], ai[k1], br, bi);
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) {
+                yr[(4 * k1 + 9 * k2) % 12] = br[k2];
+                yi[(4 * k1 + 9 * k2) % 12] = bi[k2];
+            }
+        }
+    }
+};
+
+// j mod S for a compile-time stride (a mask when S is a power of two; the 3 * 2^k plans have S = 12, 192 in their inverse passes)
+template <int S>
+__device__ __forceinline__ int mod_stride(int j) {
+    if constexpr ((S & (S - 1)) == 0)
+        return j & (S - 1);
+    else
+        return j % S;
+}
+
 // ------------------------------------------------------------------------------------------
 // LDS addressing.  The exchange written by a pass with S == 1 (runs of R contiguous elements per
 // thread) is XOR-swizzled so that 16 consecutive butterflies hit 16 different 8-byte bank pairs;
@@ -282,7 +339,9 @@ __device__ __forceinline__ int lds_phys(int a) {
     if constexpr (!SWZ) {
         return a;
     } else {
-        constexpr int mask = (R < 16 ? R : 16) - 1;
+        // R = 12 (a = 12 j + r): lanes j, j+4, j+8, j+12 of a 16-lane store group share a & 15 and sit 3 sixteen-element blocks
+        // apart: XORing the two low bits with the block index separates them (tools/emulate_lds.py checks every pass)
+        constexpr int mask = R == 12 ? 3 : (R < 16 ? R : 16) - 1;
         constexpr int sh = R <= 16 ? 4 : 5;
         return a ^ ((a >> sh) & mask);
     }
@@ -324,7 +383,7 @@ struct Pass {
         Tw3 r;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int jlo = bfly(i, tid, ja, jb) & (S - 1);
+            const int jlo = mod_stride<S>(bfly(i, tid, ja, jb));
 #pragma unroll
             for (int k = 0; k < 5; ++k) r.t[i][k] = k < TWROWS ? tw[TWOFF + k * S + jlo] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -343,7 +402,7 @@ struct Pass {
             }
             if constexpr (S > 1 && PL::tw_two_level(R, S)) {
                 // two-level twiddles: w^(Ba+b) = w^(Ba) * w^b with B = 4 (radix 16) or 8 (radix 32)
-                const int jlo = bfly(i, tid, ja, jb) & (S - 1);
+                const int jlo = mod_stride<S>(bfly(i, tid, ja, jb));
                 float4 t[5];
 #if ADSP_ABLATE & 1
 #pragma unroll
@@ -386,7 +445,7 @@ struct Pass {
                         rot(a4 + b, wr[a4] * wr[b] - wi[a4] * wi[b], wr[a4] * wi[b] + wi[a4] * wr[b]);
                 }
             } else if constexpr (S > 1) {
-                const int jlo = bfly(i, tid, ja, jb) & (S - 1);
+                const int jlo = mod_stride<S>(bfly(i, tid, ja, jb));
 #pragma unroll
                 for (int h = 0; h < R / 2; ++h) {
 #if ADSP_ABLATE & 1
@@ -426,7 +485,7 @@ struct Pass {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int j = bfly(i, tid, ja, jb);
-            const int jlo = j & (S - 1);
+            const int jlo = mod_stride<S>(j);
             const int base = (j - jlo) * R + jlo;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -443,7 +502,7 @@ struct Pass {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int j = bfly(i, tid, ja, jb);
-            const int jlo = j & (S - 1);
+            const int jlo = mod_stride<S>(j);
             const int base = (j - jlo) * R + jlo;
             if ((base >= M / 2) == (H == 1)) {
 #pragma unroll
@@ -765,8 +824,9 @@ __device__ __forceinline__ void spectrum_stage_xl(float (&xr)[PL::P], float (&xi
 
 // ------------------------------------------------------------------------------------------
 // window load / kept-sample store with compile-time chunk geometry.
-// FN = F/N (2 or 4).  MPC = P/FN registers per chunk; windows and kept ranges start on quarter-chunk
-// boundaries, so (phase RQ in 0..3, register m) -> (chunk index, offset) is known at compile time.
+// FQ = 4 F/N = the transform length in QUARTER chunks (8: F = 2N, 16: F = 4N, 6: F = 1.5 N, the 3 * 2^k plans).
+// MPC = 4P/FQ registers per chunk; windows and kept ranges start on quarter-chunk boundaries, so
+// (phase RQ in 0..3, register m) -> (chunk index, offset) is known at compile time; a window touches (FQ+3)/4 + 1 chunks.
 // ------------------------------------------------------------------------------------------
 // neighbour-lane exchange (lane ^ 1) as a DPP quad permute [1,0,3,2]
 __device__ __forceinline__ float lane_xor1(float v) {
@@ -778,11 +838,11 @@ __device__ __forceinline__ float lane_xor1(float v) {
 // odd lane 16 bytes at element tid-1 of register 2u+1 (its neighbour's + its own); one DPP swap per float puts every
 // value home.  Same bytes, half the vector-memory instructions (a dwordx2 costs the TA what a dwordx4 does).
 // `cb`/`ob` pointers passed in already carry the per-lane adjustment (+2T-2 floats on odd lanes).
-template <class PL, int FN, int RQ>
-__device__ __forceinline__ void load_window(const float* const (&cb)[FN + 1], float (&xr)[PL::P], float (&xi)[PL::P],
+template <class PL, int FQ, int RQ>
+__device__ __forceinline__ void load_window(const float* const (&cb)[(FQ + 3) / 4 + 1], float (&xr)[PL::P], float (&xi)[PL::P],
                                             bool odd, bool nt, int win_pairs) {
-    constexpr int P = PL::P, T = PL::T, MPC = P / FN, Q = MPC / 4;
-    static_assert(MPC % 4 == 0, "need at least 4 registers per chunk");
+    constexpr int P = PL::P, T = PL::T, MPC = 4 * P / FQ, Q = MPC / 4;
+    static_assert(4 * P % FQ == 0 && MPC % 4 == 0, "whole registers per quarter chunk");
     if constexpr (ADSP_WIDE_IO && Q % 2 == 0) {
         // All P/2 loads are issued before the first result is touched: left to itself the scheduler interleaves the
         // lane exchange of the first results with the address arithmetic of the last loads, which then leave one full
@@ -847,10 +907,10 @@ __device__ __forceinline__ void load_window(const float* const (&cb)[FN + 1], fl
     }
 }
 
-template <class PL, int FN, int RQ, bool EPI = false>
-__device__ __forceinline__ void store_kept(float* const (&ob)[FN + 1], const float (&xr)[PL::P],
+template <class PL, int FQ, int RQ, bool EPI = false>
+__device__ __forceinline__ void store_kept(float* const (&ob)[(FQ + 3) / 4 + 1], const float (&xr)[PL::P],
                                            const float (&xi)[PL::P], int m_lo, int m_hi, bool odd, int mix = 0) {
-    constexpr int P = PL::P, T = PL::T, MPC = P / FN, Q = MPC / 4;
+    constexpr int P = PL::P, T = PL::T, MPC = 4 * P / FQ, Q = MPC / 4;
     if constexpr (ADSP_WIDE_IO && Q % 2 == 0) {
 #pragma unroll
         for (int u = 0; u < P / 2; ++u) {
@@ -928,10 +988,10 @@ __device__ __forceinline__ unsigned pack_s16(float re, float im) {
     return a | b;
 }
 
-template <class PL, int FN, int RQ>
-__device__ __forceinline__ void load_window_s16(const unsigned* const (&cb)[FN + 1], float (&xr)[PL::P],
+template <class PL, int FQ, int RQ>
+__device__ __forceinline__ void load_window_s16(const unsigned* const (&cb)[(FQ + 3) / 4 + 1], float (&xr)[PL::P],
                                                 float (&xi)[PL::P], bool odd) {
-    constexpr int P = PL::P, T = PL::T, MPC = P / FN, Q = MPC / 4;
+    constexpr int P = PL::P, T = PL::T, MPC = 4 * P / FQ, Q = MPC / 4;
     if constexpr (ADSP_WIDE_IO && Q % 2 == 0) {
 #pragma unroll
         for (int u = 0; u < P / 2; ++u) {
@@ -954,10 +1014,10 @@ __device__ __forceinline__ void load_window_s16(const unsigned* const (&cb)[FN +
     }
 }
 
-template <class PL, int FN, int RQ>
-__device__ __forceinline__ void store_kept_s16(unsigned* const (&ob)[FN + 1], const float (&xr)[PL::P],
+template <class PL, int FQ, int RQ>
+__device__ __forceinline__ void store_kept_s16(unsigned* const (&ob)[(FQ + 3) / 4 + 1], const float (&xr)[PL::P],
                                                const float (&xi)[PL::P], int m_lo, int m_hi, bool odd) {
-    constexpr int P = PL::P, T = PL::T, MPC = P / FN, Q = MPC / 4;
+    constexpr int P = PL::P, T = PL::T, MPC = 4 * P / FQ, Q = MPC / 4;
     if constexpr (ADSP_WIDE_IO && Q % 2 == 0) {
 #pragma unroll
         for (int u = 0; u < P / 2; ++u) {
@@ -1136,12 +1196,48 @@ __device__ __forceinline__ void transform_block(float (&xr)[PL::P], float (&xi)[
 }
 
 // ------------------------------------------------------------------------------------------
+// Resident ring launches: block `step` waits until the producer side has published its chunk.  Thread 0 polls the
+// sequence word (system-scope loads: the writer is a copy engine or another kernel), gives up after seq_timeout ticks of
+// the 100 MHz clock - a consumer launched without a producer must not hang the GPU - and tells the whole workgroup through
+// LDS.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool wait_for_step(const KernelArgs& a, unsigned step, unsigned* lds_flag) {
+    if (threadIdx.x == 0) {
+        const unsigned need = a.seq_base + step + 1u;
+        unsigned ok = 1;
+        if (static_cast<int>(__hip_atomic_load(a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - need) < 0) {
+            const unsigned long long t0 = wall_clock64();
+            while (static_cast<int>(__hip_atomic_load(a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - need) < 0) {
+                __builtin_amdgcn_s_sleep(16);
+                if (wall_clock64() - t0 > a.seq_timeout) {
+                    ok = 0;
+                    __hip_atomic_store(a.seq_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+        }
+        lds_flag[0] = ok;
+    }
+    __syncthreads();
+    const unsigned ok = lds_flag[0];
+    __syncthreads();  // the flag word is part of the exchange buffer
+    // No cache invalidation is needed, only program order (the loads below may not be hoisted above the poll): a launch
+    // covers at most ring_slots - history steps, so every slot it reads is written ONCE, before the first read of it in this
+    // launch - no CU's L1 (invalidated at kernel start) and no XCD's L2 can hold an older copy fetched during the launch.
+    // An agent-scope acquire here (buffer_inv sc1 in every workgroup) cost 2.7x the whole kernel (profiles/r3_resident.txt).
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return ok != 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // the kernel: one workgroup = CPB channels x one time block
 // ------------------------------------------------------------------------------------------
-template <class PL, int CPB, int FN, bool S16 = false, bool EPI = false>
+template <class PL, int CPB, int FQ, bool S16 = false, bool EPI = false>
 __global__ __launch_bounds__(PL::T* CPB, PL::minw(!S16 && !EPI)) void fftconv_kernel(const KernelArgs a) {
     constexpr int M = PL::M, P = PL::P, T = PL::T;
-    constexpr int N = 2 * M / FN;  // chunk size
+    constexpr int N = 8 * M / FQ;  // chunk size (FQ quarter chunks per transform of 2M samples)
+    constexpr int NCH = (FQ + 3) / 4 + 1;  // chunks a window can touch
+    static_assert((N & (N - 1)) == 0, "specialised kernels: power-of-two chunks");
     constexpr int LOGN = __builtin_ctz(N);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2* lds = reinterpret_cast<float2*>(smem_raw);
@@ -1156,13 +1252,29 @@ __global__ __launch_bounds__(PL::T* CPB, PL::minw(!S16 && !EPI)) void fftconv_ke
     const int lin = static_cast<int>(blockIdx.x);
     const int xcd = lin & 7;
     const int idx = lin >> 3;
-    const int cgl = idx / a.nblk;
-    const int blk = idx - cgl * a.nblk;
+    int cgl = idx / a.nblk;
+    int blk = idx - cgl * a.nblk;
+    if (a.seq) {
+        // resident ring launches run STEP-major (every channel group of step 0, then step 1, ..): workgroups are dispatched in
+        // index order, and one that waits for a later step must not hold a CU slot before those of earlier steps have one.
+        // When every step was already published at launch time the order is tiles of 4 steps instead (every channel group of
+        // steps 0..3, then 4..7; a channel group's 4 steps are neighbours, so their window overlap is an L2 hit: -6 %)
+        const int ST = a.step_tile;  // 1 while steps are still to be published, 4 when the launch found them all published
+        const int ncgl = (a.ncg + 7) >> 3;
+        const int tile = idx / (ncgl * ST);
+        const int rem = idx - tile * (ncgl * ST);
+        cgl = rem / ST;
+        blk = tile * ST + (rem - cgl * ST);
+        if (blk >= a.nblk) return;
+    }
     const int cg = cgl * 8 + xcd;
     if (cg >= a.ncg) return;  // whole workgroup leaves together
     const int c = cg * CPB + grp;
     const bool chan_ok = CPB == 1 ? true : (c < a.C);
 
+    if (a.seq) {  // wave-uniform: a resident ring launch (V == N: block b is step b and reads nothing newer than its own chunk)
+        if (!wait_for_step(a, static_cast<unsigned>(blk), reinterpret_cast<unsigned*>(smem_raw))) return;
+    }
     const int o = blk * a.V;        // first output-time of this block (multiple of N/4)
     const int t0 = o - a.lookback;  // first input-time of the window (multiple of N/4)
     // Sample storage unit U: float (2 per element) or, for int16 PCM, one dword per element.
@@ -1170,7 +1282,7 @@ __global__ __launch_bounds__(PL::T* CPB, PL::minw(!S16 && !EPI)) void fftconv_ke
     constexpr int UPE = S16 ? 1 : 2;                                        // units per complex element
     const size_t plane = (static_cast<size_t>(a.C) << LOGN) / 2 * UPE;      // one [C][N] chunk batch, in units
     // wide I/O: odd lanes address the neighbour pair of the NEXT register (element tid-1, one register = T elements on)
-    constexpr bool WIDE = ADSP_WIDE_IO && ((P / FN) / 4) % 2 == 0;
+    constexpr bool WIDE = ADSP_WIDE_IO && ((4 * P / FQ) / 4) % 2 == 0;
     const bool odd = WIDE && (tid & 1);
     const size_t lane_off = static_cast<size_t>(UPE) * (tid + (odd ? T - 1 : 0));
 #if ADSP_ABLATE & 64
@@ -1179,19 +1291,20 @@ __global__ __launch_bounds__(PL::T* CPB, PL::minw(!S16 && !EPI)) void fftconv_ke
     const size_t chan_off = (static_cast<size_t>(c) << LOGN) / 2 * UPE + lane_off;
 #endif
 
-    // The window touches at most FN + 1 chunks.  Resolve each to a pointer once: ring history, new
+    // The window touches at most NCH chunks.  Resolve each to a pointer once: ring history, new
     // input, or the zero page for chunks that do not exist yet / channels past the end.
     const int q0 = t0 >> LOGN;  // floor: chunk of the window start, < 0 = history
-    const U* cb[FN + 1];
+    const U* cb[NCH];
 #pragma unroll
-    for (int i = 0; i < FN + 1; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int q = q0 + i;
         const U* base = static_cast<const U*>(a.zeros) + lane_off;
         if (chan_ok && q < a.n_steps) {
-            if (q < 0) {
+            if (q < 0 || a.in_ring) {
                 int slot = a.ring_pos + 1 + q;
                 slot += (slot < 0) ? a.ring_slots : 0;
                 slot = slot < 0 ? 0 : slot;  // (older than the history: never dereferenced with data that matters)
+                slot -= (slot >= a.ring_slots) ? a.ring_slots : 0;  // resident launches run ahead of ring_pos, at most one lap
                 base = static_cast<const U*>(a.ring) + static_cast<size_t>(slot) * plane + chan_off;
             } else {
                 base = static_cast<const U*>(a.in) + static_cast<size_t>(q) * plane + chan_off;
@@ -1203,17 +1316,17 @@ __global__ __launch_bounds__(PL::T* CPB, PL::minw(!S16 && !EPI)) void fftconv_ke
     float xr[P], xi[P];
     if constexpr (S16) {
         switch ((t0 & (N - 1)) >> (LOGN - 2)) {  // window phase within its first chunk, in quarter chunks
-            case 0: load_window_s16<PL, FN, 0>(cb, xr, xi, odd); break;
-            case 1: load_window_s16<PL, FN, 1>(cb, xr, xi, odd); break;
-            case 2: load_window_s16<PL, FN, 2>(cb, xr, xi, odd); break;
-            default: load_window_s16<PL, FN, 3>(cb, xr, xi, odd); break;
+            case 0: load_window_s16<PL, FQ, 0>(cb, xr, xi, odd); break;
+            case 1: load_window_s16<PL, FQ, 1>(cb, xr, xi, odd); break;
+            case 2: load_window_s16<PL, FQ, 2>(cb, xr, xi, odd); break;
+            default: load_window_s16<PL, FQ, 3>(cb, xr, xi, odd); break;
         }
     } else {
         switch ((t0 & (N - 1)) >> (LOGN - 2)) {
-            case 0: load_window<PL, FN, 0>(cb, xr, xi, odd, a.n_steps > 1, a.win_pairs); break;
-            case 1: load_window<PL, FN, 1>(cb, xr, xi, odd, a.n_steps > 1, a.win_pairs); break;
-            case 2: load_window<PL, FN, 2>(cb, xr, xi, odd, a.n_steps > 1, a.win_pairs); break;
-            default: load_window<PL, FN, 3>(cb, xr, xi, odd, a.n_steps > 1, a.win_pairs); break;
+            case 0: load_window<PL, FQ, 0>(cb, xr, xi, odd, a.n_steps > 1, a.win_pairs); break;
+            case 1: load_window<PL, FQ, 1>(cb, xr, xi, odd, a.n_steps > 1, a.win_pairs); break;
+            case 2: load_window<PL, FQ, 2>(cb, xr, xi, odd, a.n_steps > 1, a.win_pairs); break;
+            default: load_window<PL, FQ, 3>(cb, xr, xi, odd, a.n_steps > 1, a.win_pairs); break;
         }
     }
 
@@ -1227,9 +1340,9 @@ __global__ __launch_bounds__(PL::T* CPB, PL::minw(!S16 && !EPI)) void fftconv_ke
     const int m_lo = a.j0 / (2 * T), m_hi = (a.j0 + keep) / (2 * T);
     const int s = o - a.j0;
     const int k0 = s >> LOGN;  // floor
-    U* ob[FN + 1];
+    U* ob[NCH];
 #pragma unroll
-    for (int i = 0; i < FN + 1; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         int k = k0 + i;
         k = k < 0 ? 0 : (k < a.n_steps ? k : a.n_steps - 1);  // clamped ones are never stored to
         ob[i] = static_cast<U*>(a.out) + static_cast<size_t>(k) * plane + chan_off;
@@ -1237,17 +1350,17 @@ __global__ __launch_bounds__(PL::T* CPB, PL::minw(!S16 && !EPI)) void fftconv_ke
     if (chan_ok) {
         if constexpr (S16) {
             switch ((s & (N - 1)) >> (LOGN - 2)) {
-                case 0: store_kept_s16<PL, FN, 0>(ob, xr, xi, m_lo, m_hi, odd); break;
-                case 1: store_kept_s16<PL, FN, 1>(ob, xr, xi, m_lo, m_hi, odd); break;
-                case 2: store_kept_s16<PL, FN, 2>(ob, xr, xi, m_lo, m_hi, odd); break;
-                default: store_kept_s16<PL, FN, 3>(ob, xr, xi, m_lo, m_hi, odd); break;
+                case 0: store_kept_s16<PL, FQ, 0>(ob, xr, xi, m_lo, m_hi, odd); break;
+                case 1: store_kept_s16<PL, FQ, 1>(ob, xr, xi, m_lo, m_hi, odd); break;
+                case 2: store_kept_s16<PL, FQ, 2>(ob, xr, xi, m_lo, m_hi, odd); break;
+                default: store_kept_s16<PL, FQ, 3>(ob, xr, xi, m_lo, m_hi, odd); break;
             }
         } else {
             switch ((s & (N - 1)) >> (LOGN - 2)) {
-                case 0: store_kept<PL, FN, 0, EPI>(ob, xr, xi, m_lo, m_hi, odd, a.accumulate); break;
-                case 1: store_kept<PL, FN, 1, EPI>(ob, xr, xi, m_lo, m_hi, odd, a.accumulate); break;
-                case 2: store_kept<PL, FN, 2, EPI>(ob, xr, xi, m_lo, m_hi, odd, a.accumulate); break;
-                default: store_kept<PL, FN, 3, EPI>(ob, xr, xi, m_lo, m_hi, odd, a.accumulate); break;
+                case 0: store_kept<PL, FQ, 0, EPI>(ob, xr, xi, m_lo, m_hi, odd, a.accumulate); break;
+                case 1: store_kept<PL, FQ, 1, EPI>(ob, xr, xi, m_lo, m_hi, odd, a.accumulate); break;
+                case 2: store_kept<PL, FQ, 2, EPI>(ob, xr, xi, m_lo, m_hi, odd, a.accumulate); break;
+                default: store_kept<PL, FQ, 3, EPI>(ob, xr, xi, m_lo, m_hi, odd, a.accumulate); break;
             }
         }
     }

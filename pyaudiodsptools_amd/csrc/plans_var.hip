@@ -7,20 +7,21 @@
 namespace {
 using namespace adsp;
 const PlanInfo kVariants[] = {
-    make_plan<Plan<4096, 32, 3, 16, 16, 16, 1>, 1, 2, false, false>(),         // 0: headline size, in-register pairing, 2 waves/transform, ~190 VGPRs (-8 %)
-    make_plan<Plan<16384, 32, 4, 32, 2, 16, 16>, 1, 4, false, false>(),        // 1: M = 16384 in four passes (-8 % against 4)
-    make_plan<Plan<16384, 16, 4, 4, 16, 16, 16, true>, 1, 4, false, false>(),  // 2: XL, 1024 threads, 16 points per thread (-8 % against 4)
-    make_plan<Plan<16384, 16, 4, 16, 4, 16, 16, true>, 1, 4, false, false>(),  // 3: same, radix 4 second (= 4)
-    make_plan<Plan<16384, 32, 3, 32, 32, 16, 1>, 1, 4, false, false>(),        // 4: the round-1 plan: 32 points per thread, ONE workgroup per CU (-12 % against the default)
-    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1, 2, false, false>(),         // 5: the round-1 plan: full exchange, 186 VGPRs, TWO workgroups per CU (-8 %)
-    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1, 4, false, false>(),         // 6: same, F = 4N (-9 %)
-    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1, false, true, 2>, 1, 2, false, false>(),   // 7: half exchange alone, still two workgroups per CU: the price of its barriers (-6 % against 5)
-    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true, true, 5>, 1, 2, false, false>(),    // 8: headline plan, 16 KiB of LDS, FIVE workgroups per CU at 96 VGPRs (-9 %; six at 80 VGPRs: -20 %)
-    make_plan<Plan<16384, 64, 3, 32, 32, 16, 1, false, true, 2>, 1, 4, false, false>(),  // 9: 64 points per thread with paired passes of radix 16 (2 pairs of butterflies per thread): 76 instead of 120 bytes of scratch, -4 %
-    make_plan<Plan<512, 32, 2, 32, 16, 1, 1>, 4, 2, false, false>(),                     // 10: config 3's stream transform in TWO passes (32 points per thread, 16 threads per transform): stream 10.4 us per step instead of 7.8
-    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1, false, true, 3>, 1, 2, false, false>(),   // 11: the round-2 default for M = 8192: three workgroups per CU (round 3: FOUR at 128 VGPRs + 12 B of scratch, once the spectrum stage had lost its else branches: +5 %)
-    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1, false, true, 3>, 1, 4, false, false>(),   // 12: same, F = 4N (four: +3 %)
-    make_plan<Plan<16384, 32, 3, 32, 32, 16, 1, false, true, 4>, 1, 4, false, false>(),  // 13: M = 16384 with 32 points per thread in 512 threads, half exchange: two workgroups of eight waves per CU at 128 VGPRs (48 B of scratch)
+    make_plan<Plan<4096, 32, 3, 16, 16, 16, 1>, 1, 8, false, false>(),         // 0: headline size, in-register pairing, 2 waves/transform, ~190 VGPRs (-8 %)
+    make_plan<Plan<16384, 32, 4, 32, 2, 16, 16>, 1, 16, false, false>(),        // 1: M = 16384 in four passes (-8 % against 4)
+    make_plan<Plan<16384, 16, 4, 4, 16, 16, 16, true>, 1, 16, false, false>(),  // 2: XL, 1024 threads, 16 points per thread (-8 % against 4)
+    make_plan<Plan<16384, 16, 4, 16, 4, 16, 16, true>, 1, 16, false, false>(),  // 3: same, radix 4 second (= 4)
+    make_plan<Plan<16384, 32, 3, 32, 32, 16, 1>, 1, 16, false, false>(),        // 4: the round-1 plan: 32 points per thread, ONE workgroup per CU (-12 % against the default)
+    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1, 8, false, false>(),         // 5: the round-1 plan: full exchange, 186 VGPRs, TWO workgroups per CU (-8 %)
+    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1>, 1, 16, false, false>(),         // 6: same, F = 4N (-9 %)
+    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1, false, true, 2>, 1, 8, false, false>(),   // 7: half exchange alone, still two workgroups per CU: the price of its barriers (-6 % against 5)
+    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true, true, 5>, 1, 8, false, false>(),    // 8: headline plan, 16 KiB of LDS, FIVE workgroups per CU at 96 VGPRs (-9 %; six at 80 VGPRs: -20 %)
+    make_plan<Plan<16384, 64, 3, 32, 32, 16, 1, false, true, 2>, 1, 16, false, false>(),  // 9: 64 points per thread with paired passes of radix 16 (2 pairs of butterflies per thread): 76 instead of 120 bytes of scratch, -4 %
+    make_plan<Plan<512, 32, 2, 32, 16, 1, 1>, 4, 8, false, false>(),                     // 10: config 3's stream transform in TWO passes (32 points per thread, 16 threads per transform): stream 10.4 us per step instead of 7.8
+    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1, false, true, 3>, 1, 8, false, false>(),   // 11: the round-2 default for M = 8192: three workgroups per CU (round 3: FOUR at 128 VGPRs + 12 B of scratch, once the spectrum stage had lost its else branches: +5 %)
+    make_plan<Plan<8192, 32, 3, 32, 16, 16, 1, false, true, 3>, 1, 16, false, false>(),   // 12: same, F = 4N (four: +3 %)
+    make_plan<Plan<16384, 32, 3, 32, 32, 16, 1, false, true, 4>, 1, 16, false, false>(),  // 13: M = 16384 with 32 points per thread in 512 threads, half exchange: two workgroups of eight waves per CU at 128 VGPRs (48 B of scratch)
+    make_plan<Plan<3072, 48, 3, 16, 16, 12, 1, false, true, 3>, 1, 6, false, false>(),    // 14: the 3 * 2^k plan at three waves per SIMD (168 VGPRs, 100 B of scratch)
 };
 // also measured and dropped: M = 8192 at four workgroups per CU / 128 VGPRs (spills, = 5), 64 points per thread for M = 8192
 // (-3 % against 5), M = 8192 with radix-16 paired passes (-7 %), one wave per transform with 8 points per thread for M = 512

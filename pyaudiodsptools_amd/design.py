@@ -130,14 +130,14 @@ class Geometry:
     zero_phase: bool = False  # the spectrum is real: the engine takes its 3-constants-per-bin-pair path
 
 
-def overlap_save_geometry(fir: FirStream, fft_mult: int = 0, optimize_for: str = "stream") -> Geometry:
+def overlap_save_geometry(fir: FirStream, fft_mult: float = 0, optimize_for: str = "stream") -> Geometry:
     """Choose F, the window position and the kept slice for the GPU engine (include/adsp.h).
 
     Output tau is y[tau - D] with y = taps (*) s and D = delay.  The window for the block starting at
     output-time o begins at input-time o - lookback, so output tau sits at circular index
     (tau - o) + lookback - D + shift; it is wrap-free when lookback >= D + len(taps) - 1.
     Everything is kept a multiple of N/4 (>= 2 * threads-per-transform for every plan).
-    fft_mult = 4 forces a 4N transform (fewer, larger blocks in multi-step launches); optimize_for="batch"
+    fft_mult = 4 forces a 4N transform (fewer, larger blocks in multi-step launches), 1.5 / 2 likewise; optimize_for="batch"
     picks 4N by itself when a 2N transform keeps only half of its samples (EQ: measured +15 % in multi-step launches).
     """
     n = int(fir.chunk_size)
@@ -163,7 +163,11 @@ def overlap_save_geometry(fir: FirStream, fft_mult: int = 0, optimize_for: str =
     out_offset = lookback - d_total + shift
     if not fft_mult and optimize_for == "batch" and (2 * n - max(0, -shift) - out_offset) // g * g <= n and out_offset + n <= 4 * n - max(0, -shift):
         fft_mult = 4
-    for f in ((2 * n, 4 * n) if not fft_mult else (fft_mult * n,)):
+    # fft_mult = 1.5 (F = 3 * 2^k, where libadsp has such a plan: N = 4096) is all a single-step launch of the reference's cut
+    # filters needs (N + 2d samples): 27 % less butterfly work per kept chunk than a 2N transform.  It is opt-in: its plan runs
+    # one wave per transform and only beats the 2N plan with >= 8192 channels per GPU.
+    candidates = (2 * n, 4 * n) if not fft_mult else (int(round(fft_mult * n)),)
+    for f in candidates:
         if out_offset + n <= f - max(0, -shift):
             break
     else:

@@ -35,7 +35,7 @@ class FirEngine:
         self._lib = _capi.load()
         self._h = ctypes.c_void_p(None)
         self.fir = fir
-        self.fft_mult = int(fft_mult)
+        self.fft_mult = fft_mult if fft_mult != int(fft_mult) else int(fft_mult)
         if sample_format not in _FORMATS:
             raise ValueError("sample_format must be 'f32' or 's16'")
         self.sample_format = sample_format
@@ -179,6 +179,29 @@ class FirEngine:
     def ring_reset_order(self):
         """Drain the device and forget the cross-stream ordering events of the ring (before and after hipGraph capture)."""
         _capi.check(self._lib.adsp_ring_reset_order(self._h))
+
+    # resident ring launches (include/adsp.h): the producer publishes steps, one consumer launch covers many of them
+    def ring_produce_begin(self, stream=None):
+        p = ctypes.c_void_p(None)
+        _capi.check(self._lib.adsp_ring_produce_begin(self._h, ctypes.byref(p), _ptr(stream)))
+        return p.value
+
+    def ring_produce_end(self, stream=None):
+        _capi.check(self._lib.adsp_ring_produce_end(self._h, _ptr(stream)))
+
+    def apply_ring_resident(self, d_out, n_steps, stream=None):
+        """d_out [n_steps, C, N]: consumes the next n_steps ring steps in ONE launch; step k's workgroups start when the
+        producer has published it (ring_produce_begin / _end), which may happen after this call."""
+        _capi.check(self._lib.adsp_apply_ring_resident(self._h, _ptr(d_out), int(n_steps), _ptr(stream)))
+
+    def ring_resident_timeout(self, milliseconds):
+        _capi.check(self._lib.adsp_ring_resident_timeout(self._h, float(milliseconds)))
+
+    def ring_resident_timed_out(self):
+        """True (once) when a workgroup of a resident launch gave up waiting for its step; synchronises on the flag."""
+        v = ctypes.c_int(0)
+        _capi.check(self._lib.adsp_ring_resident_status(self._h, ctypes.byref(v)))
+        return bool(v.value)
 
     def apply_ring(self, d_out, stream=None):
         _capi.check(self._lib.adsp_apply_ring(self._h, _ptr(d_out), _ptr(stream)))

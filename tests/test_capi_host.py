@@ -34,7 +34,11 @@ def test_plans_cover_supported_chunk_sizes():
             full = d["channels_per_workgroup"] * (f // 2) * 8  # one complex64 per point; the large transforms exchange through half a buffer
             assert d["lds_bytes"] == (full // 2 if f // 2 >= 8192 else full) <= 64 * 1024
             assert (n // 4) % (2 * d["threads_per_transform"]) == 0  # design.py's N/4 granularity is legal
-    assert lib.adsp_plan_supported(3000, 6000) != 0   # transforms are powers of two
+    assert lib.adsp_plan_supported(3000, 6000) != 0   # transforms are powers of two ...
+    assert lib.adsp_plan_supported(4096, 6144) == 0   # ... or 1.5 x a power-of-two chunk that has a 3 * 2^k plan (M = 3072)
+    d = _capi.plan_describe(4096, 6144)
+    assert (d["complex_points"], d["points_per_thread"], d["threads_per_transform"], d["lds_bytes"]) == (3072, 48, 64, 3072 * 8 // 2)
+    assert lib.adsp_plan_supported(512, 768) != 0 and lib.adsp_plan_supported(1000, 6144) != 0
     assert lib.adsp_plan_supported(32, 64) != 0       # ... of at least 128 points
     assert lib.adsp_plan_supported(3002, 8192) != 0   # chunk must be a multiple of 4
     assert lib.adsp_plan_supported(3000, 8192) == 0   # generic geometry: any such chunk with any supported transform
@@ -46,10 +50,16 @@ def test_geometry_matches_header_documentation():
     from pyaudiodsptools_amd import design
     for n in (64, 512, 4096, 8192):
         lc = design.FirStream(design.lowcut_kernel(800, 44100, n), n)
-        g = design.overlap_save_geometry(lc)
+        g = design.overlap_save_geometry(lc, 2)
         # symmetric kernel centred on circular index 0 (real spectrum): the kept slice starts after d = N/4 - 1 wrapped taps
         assert (g.fft_size, g.history_chunks, g.lookback, g.out_offset, g.shift, g.max_block_outputs, g.zero_phase) == \
             (2 * n, 2, n + n // 4, n // 4, -(n // 4 - 1), n + n // 2, True)
+        assert design.overlap_save_geometry(lc, 0, "batch") == g  # multi-step launches: 1.5 N kept per 2N transform
+        assert design.overlap_save_geometry(lc) == g
+        if n == 4096:  # opt-in: the minimal window N + 2d = 1.5 N of single-step launches (the 3 * 2^k plan, M = 3072)
+            gs = design.overlap_save_geometry(lc, 1.5)
+            assert (gs.fft_size, gs.history_chunks, gs.lookback, gs.out_offset, gs.shift, gs.max_block_outputs, gs.zero_phase) == \
+                (3 * n // 2, 2, n + n // 4, n // 4, -(n // 4 - 1), n, True)
         spec = design.engine_spectrum(lc, g)
         assert np.all(spec[1::2] == 0) and np.abs(spec[0::2]).max() > 0.5
         eq = design.FirStream(design.eq3_composite(100, 2, 700, -4, 8000, 5, 44100, n), n)

@@ -1,6 +1,8 @@
 """Pin the CPU oracle (oracle/fftfilter_oracle.py) against vectors captured from the real reference."""
 import hashlib
 
+import os
+
 import numpy as np
 import pytest
 
@@ -110,6 +112,25 @@ def test_example1_plumbing_F(golden):
     chunks = orc.make_chunks(np.zeros(264600, np.float32), 4096)
     assert len(chunks) == 65 and sum(len(c) for c in chunks) == int(g["out_len"][0]) == 266240
     assert len(orc.combine_chunks(chunks)) == 266240
+
+
+def test_example1_full_run_hash():
+    """the whole of Example1.py (65 chunks, 1640 padded zeros, last input chunk never flushed) through the
+    oracle reproduces the reference's merged output - bit for bit (sha256 prefix 9c38cf3169419998) under the numpy the
+    fixture was made with, to 1e-6 of full scale under any other."""
+    import hashlib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_example1_full.npz"))
+    full = g["pcm16"].astype(np.float32) / 32768
+    chunks = orc.make_chunks(full, 4096)
+    assert len(chunks) == int(g["n_chunks"][0]) == 65 and not chunks[-1][-1640:].any() and len(chunks[-1]) == 4096
+    dev = orc.OracleLowCut(800, 44100, 4096)
+    outs = [dev.apply(c) for c in chunks]
+    merged = orc.combine_chunks(outs)
+    assert len(merged) == int(g["out_len"][0]) == 266240
+    assert np.abs(merged[::8] - g["out_dec8"]).max() <= 1e-6
+    assert np.abs(outs[0] - g["out_first_chunk"]).max() <= 1e-6 and np.abs(outs[-1] - g["out_last_chunk"]).max() <= 1e-6
+    if np.__version__ == bytes(g["numpy_version"]).decode():
+        assert hashlib.sha256(merged.astype(np.float32).tobytes()).hexdigest()[:16] == bytes(g["sha16"]).decode() == "9c38cf3169419998"
 
 
 EDGE_INPUTS = {
