@@ -387,6 +387,7 @@ def resident_figures(args, fir, dev, alg_bytes, channels, chunk, launches=24, st
             for _ in range(n):  # the (data-less) producer: takes the n slots in turn ...
                 eng.ring_produce_begin(prod)
             eng.ring_produce_end(prod)  # ... and publishes them with one write of the sequence word
+            cons.wait_stream(prod)      # publish first: a grid this large must not wait in-kernel (adsp.h, LIMITATION)
             eng.apply_ring_resident(out, n, sptr)
     t_pre = time.perf_counter()
     while (time.perf_counter() - t_pre) * 1e3 < prewarm_ms:

@@ -161,8 +161,14 @@ def overlap_save_geometry(fir: FirStream, fft_mult: float = 0, optimize_for: str
     else:
         shift = (-(lookback - d_total)) % g
     out_offset = lookback - d_total + shift
-    if not fft_mult and optimize_for == "batch" and (2 * n - max(0, -shift) - out_offset) // g * g <= n and out_offset + n <= 4 * n - max(0, -shift):
-        fft_mult = 4
+    if not fft_mult and optimize_for == "batch" and out_offset + n <= 4 * n - max(0, -shift):
+        # Multi-step launches: a 4N transform keeps a larger share of its samples (cut filters: 3.5 N of 4 N against 1.5 N of
+        # 2 N; EQ: 3 N against N).  It is chosen when the 2N transform would keep a chunk or less (measured +15 %), and for
+        # N = 1024 .. 4096 whenever it fits: there the 4N transform runs on the M = 2048 .. 8192 plans, which are as fast per
+        # point as the 2N ones (measured on MI355X, profiles/r3_shapes_4n.txt: +13 % at N = 4096, +7 % at 1024, +4 % at 2048;
+        # -4 % at N = 512, and N = 8192 would need the slow M = 16384 plan).
+        if (2 * n - max(0, -shift) - out_offset) // g * g <= n or n in (1024, 2048, 4096):
+            fft_mult = 4
     # fft_mult = 1.5 (F = 3 * 2^k, where libadsp has such a plan: N = 4096) is all a single-step launch of the reference's cut
     # filters needs (N + 2d samples): 27 % less butterfly work per kept chunk than a 2N transform.  It is opt-in: its plan runs
     # one wave per transform and only beats the 2N plan with >= 8192 channels per GPU.

@@ -54,7 +54,12 @@ def test_geometry_matches_header_documentation():
         # symmetric kernel centred on circular index 0 (real spectrum): the kept slice starts after d = N/4 - 1 wrapped taps
         assert (g.fft_size, g.history_chunks, g.lookback, g.out_offset, g.shift, g.max_block_outputs, g.zero_phase) == \
             (2 * n, 2, n + n // 4, n // 4, -(n // 4 - 1), n + n // 2, True)
-        assert design.overlap_save_geometry(lc, 0, "batch") == g  # multi-step launches: 1.5 N kept per 2N transform
+        gb = design.overlap_save_geometry(lc, 0, "batch")  # multi-step launches: 1.5 N kept per 2N transform, or, where the
+        if n == 4096:                                         # 4N transform runs on a fast plan (N = 1024..4096), 3.5 N of 4 N
+            assert (gb.fft_size, gb.history_chunks, gb.lookback, gb.out_offset, gb.shift, gb.max_block_outputs, gb.zero_phase) == \
+                (4 * n, 2, n + n // 4, n // 4, -(n // 4 - 1), 3 * n + n // 2, True)
+        else:
+            assert gb == g
         assert design.overlap_save_geometry(lc) == g
         if n == 4096:  # opt-in: the minimal window N + 2d = 1.5 N of single-step launches (the 3 * 2^k plan, M = 3072)
             gs = design.overlap_save_geometry(lc, 1.5)
