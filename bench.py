@@ -71,7 +71,7 @@ def parse(argv=None):
     ap.add_argument("--ring-slots", type=int, default=0, help="stream mode: input ring length (0 = history + 1, the smallest; "
                     "3 slots x 64 MiB stay inside the 256 MB Infinity Cache at the default shape)")
     ap.add_argument("--fft-mult", type=float, default=0, help="force transform length = this multiple of the chunk (1.5, 2 or 4; 0 = the library's choice)")
-    ap.add_argument("--io", default="f32", choices=["f32", "s16"],
+    ap.add_argument("--io", default="f32", choices=["f32", "s16", "s16_f64"],
                     help="sample format of the resident batches: float32 (headline) or int16 PCM (fused WAV front end, 4 B/sample)")
     ap.add_argument("--effect", default="none", choices=["none", "softclip", "harddist", "saturator", "volume", "tremolo"],
                     help="fuse a stateless wave-shaper on the kernel's output (not part of the headline workload)")
@@ -174,7 +174,7 @@ class Runner:
         gen = torch.Generator(device=dev)
         gen.manual_seed(1234 + rank)
         amp = float(os.environ.get("ADSP_BENCH_AMPLITUDE", "1"))  # tuning only: 0 = all-zero data (DVFS check)
-        s16 = args.io == "s16"
+        s16 = args.io != "f32"
         dt = torch.int16 if s16 else torch.float32
         self.graph = None
 
@@ -366,13 +366,13 @@ def resident_figures(args, fir, dev, alg_bytes, channels, chunk, launches=24, st
     # 2 n + history slots: the producer fills the slots of launch L + 1 while launch L runs (it only ever waits for launch L - 1)
     eng = FirEngine(fir, channels=C, device=dev.index, ring_slots=2 * n + geo.history_chunks, fft_mult=args.fft_mult,
                     sample_format=args.io, optimize_for="stream")
-    dt = torch.int16 if args.io == "s16" else torch.float32
+    dt = torch.int16 if args.io != "f32" else torch.float32
     gen = torch.Generator(device=dev)
     gen.manual_seed(4321)
     scratch = torch.empty((C, N), device=dev, dtype=dt)
     sptr = torch.cuda.current_stream(dev).cuda_stream
     for _ in range(eng.ring_slots):  # set-up: every slot holds synthetic data
-        batch = (torch.randint(-16384, 16384, (C, N), device=dev, dtype=torch.int16, generator=gen) if args.io == "s16"
+        batch = (torch.randint(-16384, 16384, (C, N), device=dev, dtype=torch.int16, generator=gen) if args.io != "f32"
                  else torch.empty((C, N), device=dev, dtype=torch.float32).uniform_(-1, 1, generator=gen))
         eng.apply_device(batch, scratch, 1, sptr)
     torch.cuda.synchronize(dev)
@@ -621,7 +621,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.io == "f32" else "f32 arithmetic on s16 samples",
+            "dtype": {"f32": "f32", "s16": "f32 arithmetic on s16 samples", "s16_f64": "f64 arithmetic on s16 samples"}[args.io],
             "data": ("synthetic uniform(-1,1) float32" if args.io == "f32" else "synthetic uniform int16 PCM (-6 dBFS)") + " resident in HBM " +
                     ("(library input ring)" if args.mode == "stream" else "([chunks, channels, chunk] batches)"),
             "config": {"workload": f"{FILTER_NAMES[args.filter]}{'' if args.effect == 'none' else ' -> ' + args.effect} @ {args.fs} Hz, {C} mono channels x {N}-sample chunks per GPU",

@@ -41,7 +41,7 @@ extern "C" {
 #define ADSP_API
 #endif
 
-#define ADSP_ABI_VERSION 6
+#define ADSP_ABI_VERSION 7
 #define ADSP_MAX_HISTORY 8
 
 typedef enum adsp_status {
@@ -60,6 +60,13 @@ typedef struct adsp_engine adsp_engine; /* opaque.  Engines (and delay lines, sc
 #define ADSP_FORMAT_S16 1 /* int16 PCM, the reference's WAV format: the kernel converts (float)x on load and
                              (int16)trunc(y) on store - Utility.py:233-238 (/32768) and :295-312 (*32767,
                              astype int16) become ONE factor 32767/32768 folded into the spectrum by the host */
+#define ADSP_FORMAT_S16_F64 2 /* int16 PCM batches filtered in FLOAT64 (the float64 instantiation of the same kernels): the
+                                 "exact FFT" engines.  The conversions are the reference's to the letter - float32(pcm) / 32768
+                                 in, int16(trunc(float32(y) * 32767)) out (Utility.py:236-237, :306; the spectrum carries NO
+                                 gain) - and the float64 transform's error (1e-15 of full scale) is far below the reference's
+                                 own, so the int16 stream equals the float64 direct sum of adsp_exact_* except where y lies
+                                 within ~1e-15 of a float32 rounding boundary (about one sample in 1e7).  Give the spectrum
+                                 with adsp_set_spectrum_f64.  About a third of the float32 engines' rate. */
 
 /*
  * Geometry of one streaming FIR engine.
@@ -88,7 +95,7 @@ typedef struct adsp_config {
     int out_offset;      /* see above; multiple of N/4 (specialised) or 4*threads_per_transform (generic) */
     int ring_slots;      /* input ring length (>= history_chunks+1); 0 = 2*history_chunks, which lets the ring
                             update of multi-step launches run on a side stream beside the kernel */
-    int sample_format;   /* ADSP_FORMAT_F32 or ADSP_FORMAT_S16: type of every `in`/`out`/ring/state buffer below */
+    int sample_format;   /* ADSP_FORMAT_F32, ADSP_FORMAT_S16 or ADSP_FORMAT_S16_F64 (int16 buffers): type of every `in`/`out`/ring/state buffer below */
 } adsp_config;
 
 /* ABI version (ADSP_ABI_VERSION of the built library). */
@@ -118,6 +125,10 @@ ADSP_API int adsp_destroy(adsp_engine* engine);
  * four EQ spectra + per-call recombination (EffectEQ3BandFFT.py:88-143, :182-188).  May be called
  * again at any time to change the filter (takes effect for the next apply). */
 ADSP_API int adsp_set_spectrum(adsp_engine* engine, const float* spectrum_interleaved, int n_bins);
+
+/* The same from a float64 spectrum (interleaved re, im doubles): what ADSP_FORMAT_S16_F64 engines want - their tables are
+ * built and kept in float64; a float32 / int16 engine rounds it to float32 first.  Set-up path like adsp_set_spectrum. */
+ADSP_API int adsp_set_spectrum_f64(adsp_engine* engine, const double* spectrum_interleaved, int n_bins);
 
 /* The same filter change in a LIVE stream: the tables are staged in pinned memory and copied on `stream`, so launches
  * already queued there finish with the old filter, later ones use the new one, and nothing else is waited for (no

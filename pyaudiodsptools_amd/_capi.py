@@ -6,9 +6,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADSP_LIB") or os.path.join(_HERE, "libadsp.so")  # ADSP_LIB: tuning builds only
 
-ADSP_ABI_VERSION = 6
+ADSP_ABI_VERSION = 7
 ADSP_MAX_HISTORY = 8
-ADSP_FORMAT_F32, ADSP_FORMAT_S16 = 0, 1
+ADSP_FORMAT_F32, ADSP_FORMAT_S16, ADSP_FORMAT_S16_F64 = 0, 1, 2
 EFFECT_NONE, EFFECT_VOLUME, EFFECT_SOFT_CLIPPER, EFFECT_HARD_DISTORTION, EFFECT_SATURATOR, EFFECT_TREMOLO = 0, 1, 2, 3, 4, 5
 EFFECT_BIT_CRUSHER = 6
 ADSP_OK, ADSP_ERR_ARG, ADSP_ERR_HIP, ADSP_ERR_STATE, ADSP_ERR_NO_DEVICE = 0, -1, -2, -3, -4
@@ -63,6 +63,7 @@ SIGNATURES = {
     "adsp_create": (ctypes.c_int, [ctypes.POINTER(AdspConfig), ctypes.POINTER(_engine_p)]),
     "adsp_destroy": (ctypes.c_int, [_engine_p]),
     "adsp_set_spectrum": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_int]),
+    "adsp_set_spectrum_f64": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_int]),
     "adsp_set_spectrum_async": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "adsp_set_spectrum_device": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "adsp_set_kernel_reach": (ctypes.c_int, [_engine_p, ctypes.c_int]),

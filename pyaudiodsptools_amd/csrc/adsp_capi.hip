@@ -124,7 +124,7 @@ const PlanInfo* find_plan(int M, int FQ, int fmt) {
             if (i >= 0 && i < n && var[i].M == M && var[i].FQ == FQ) return &var[i];
         }
     }
-    const PlanInfo* tab = fmt == ADSP_FORMAT_S16 ? adsp::plans_s16(&n) : adsp::plans_f32(&n);
+    const PlanInfo* tab = fmt == ADSP_FORMAT_S16_F64 ? adsp::plans_s16_f64(&n) : fmt == ADSP_FORMAT_S16 ? adsp::plans_s16(&n) : adsp::plans_f32(&n);
     for (int i = 0; i < n; ++i)
         if (tab[i].M == M && tab[i].FQ == FQ) return &tab[i];
     return nullptr;
@@ -132,7 +132,7 @@ const PlanInfo* find_plan(int M, int FQ, int fmt) {
 
 const PlanInfo* find_plan_any_fn(int M, int fmt) {
     int n = 0;
-    const PlanInfo* tab = fmt == ADSP_FORMAT_S16 ? adsp::plans_s16(&n) : adsp::plans_f32(&n);
+    const PlanInfo* tab = fmt == ADSP_FORMAT_S16_F64 ? adsp::plans_s16_f64(&n) : fmt == ADSP_FORMAT_S16 ? adsp::plans_s16(&n) : adsp::plans_f32(&n);
     for (int i = 0; i < n; ++i)
         if (tab[i].M == M) return &tab[i];
     return nullptr;
@@ -148,7 +148,8 @@ int ilog2(int v) {
 // Two kinds of geometry: "specialised" (chunk a power of two in 64..8192, F = 2N or 4N: chunk boundaries are
 // compile-time constants in the kernel) and "generic" (any chunk divisible by 4, any supported power-of-two F).
 int check_geometry(int N, int F, int fmt, const PlanInfo** out, bool* generic) {
-    if (fmt != ADSP_FORMAT_F32 && fmt != ADSP_FORMAT_S16) return fail(ADSP_ERR_ARG, "sample_format %d: need ADSP_FORMAT_F32 or ADSP_FORMAT_S16", fmt);
+    if (fmt != ADSP_FORMAT_F32 && fmt != ADSP_FORMAT_S16 && fmt != ADSP_FORMAT_S16_F64)
+        return fail(ADSP_ERR_ARG, "sample_format %d: need ADSP_FORMAT_F32, ADSP_FORMAT_S16 or ADSP_FORMAT_S16_F64", fmt);
     if (N < 16 || N % 4) return fail(ADSP_ERR_ARG, "chunk_size %d: need a multiple of 4, >= 16", N);
     const bool three = F % 3 == 0 && is_pow2(F / 3);  // 3 * 2^k: the 1.5 N windows of the specialised kernels only
     if (!(is_pow2(F) || three) || F < 128 || F > 32768)
@@ -164,11 +165,32 @@ int check_geometry(int N, int F, int fmt, const PlanInfo** out, bool* generic) {
 
 // forward-sign twiddles for passes 1.. of the forward then the inverse radix order
 // float4 entries (w_{2h+1}, w_{2h+2}) indexed [h * S + jlo], h < R/2; the last one's second half is unused
-void build_twiddles(const PlanInfo& pl, std::vector<float4>& tw) {
+// (R = float, or double for the f64 flavour of the kernels: ADSP_FORMAT_S16_F64 engines)
+template <class R>
+struct Vec;
+template <>
+struct Vec<float> {
+    using T2 = float2;
+    using T4 = float4;
+    static T2 m2(double a, double b) { return make_float2((float)a, (float)b); }
+    static T4 m4(double a, double b, double c, double d) { return make_float4((float)a, (float)b, (float)c, (float)d); }
+};
+template <>
+struct Vec<double> {
+    using T2 = double2;
+    using T4 = double4;
+    static T2 m2(double a, double b) { return make_double2(a, b); }
+    static T4 m4(double a, double b, double c, double d) { return make_double4(a, b, c, d); }
+};
+
+template <class RT>
+void build_twiddles(const PlanInfo& pl, std::vector<typename Vec<RT>::T4>& tw) {
+    using V = Vec<RT>;
+    using T2 = typename V::T2;
     tw.clear();
     auto tw1 = [](int q, int jlo, int R, int S) {
         const double ang = -2.0 * M_PI * (double)q * (double)jlo / ((double)R * (double)S);
-        return make_float2((float)std::cos(ang), (float)std::sin(ang));
+        return V::m2(std::cos(ang), std::sin(ang));
     };
     for (int dir = 0; dir < 2; ++dir) {
         int S = 1;
@@ -179,23 +201,23 @@ void build_twiddles(const PlanInfo& pl, std::vector<float4>& tw) {
                 const int qs[3][2] = {{1, 2}, {3, 4}, {8, 12}};
                 for (int h = 0; h < 3; ++h)
                     for (int jlo = 0; jlo < S; ++jlo) {
-                        const float2 a = tw1(qs[h][0], jlo, R, S), b = tw1(qs[h][1], jlo, R, S);
-                        tw.push_back(make_float4(a.x, a.y, b.x, b.y));
+                        const T2 a = tw1(qs[h][0], jlo, R, S), b = tw1(qs[h][1], jlo, R, S);
+                        tw.push_back(V::m4(a.x, a.y, b.x, b.y));
                     }
             } else if (p > 0 && R == 32 && ADSP_TW2_RADIX32 && S >= ADSP_TW2_MIN_S) {
                 // two-level, radix 32: w^1..w^8, w^16, w^24 per jlo; the kernel forms w^(8a+b) = w^(8a) w^b
                 const int qs[5][2] = {{1, 2}, {3, 4}, {5, 6}, {7, 8}, {16, 24}};
                 for (int h = 0; h < 5; ++h)
                     for (int jlo = 0; jlo < S; ++jlo) {
-                        const float2 a = tw1(qs[h][0], jlo, R, S), b = tw1(qs[h][1], jlo, R, S);
-                        tw.push_back(make_float4(a.x, a.y, b.x, b.y));
+                        const T2 a = tw1(qs[h][0], jlo, R, S), b = tw1(qs[h][1], jlo, R, S);
+                        tw.push_back(V::m4(a.x, a.y, b.x, b.y));
                     }
             } else if (p > 0) {
                 for (int h = 0; h < R / 2; ++h)
                     for (int jlo = 0; jlo < S; ++jlo) {
-                        const float2 a = tw1(2 * h + 1, jlo, R, S);
-                        const float2 b = (2 * h + 2 < R) ? tw1(2 * h + 2, jlo, R, S) : make_float2(1.f, 0.f);
-                        tw.push_back(make_float4(a.x, a.y, b.x, b.y));
+                        const T2 a = tw1(2 * h + 1, jlo, R, S);
+                        const T2 b = (2 * h + 2 < R) ? tw1(2 * h + 2, jlo, R, S) : V::m2(1.0, 0.0);
+                        tw.push_back(V::m4(a.x, a.y, b.x, b.y));
                     }
             }
             S *= R;
@@ -203,24 +225,26 @@ void build_twiddles(const PlanInfo& pl, std::vector<float4>& tw) {
     }
 }
 
+template <class R>
 struct PairEntry {
-    float2 wc, g1, g2;
+    typename Vec<R>::T2 wc, g1, g2;
 };
 
-PairEntry pair_entry(const float* H, int M, int k) {
+template <class R, class HT>
+PairEntry<R> pair_entry(const HT* H, int M, int k) {
     // the three entries (c1, c2, c4) of the 2x2 matrix of fftconv_kernel.hpp::pair_op, stored as (wc, g1, g2):
     //   wc' = -i exp(-i pi k/M), g1 = H[k]/4M, g2 = conj(H[M-k])/4M, s = g1+g2, d = g1-g2
     //   c1 = 2s + 2d Re(wc'), c2 = -2i d Im(wc'), c4 = 2s - 2d Re(wc')
     const double ang = M_PI * (double)k / (double)M;
     const double sc = 1.0 / (4.0 * (double)M);
     const double wr = -std::sin(ang), wi = -std::cos(ang);
-    const double g1r = H[2 * k] * sc, g1i = H[2 * k + 1] * sc;
-    const double g2r = H[2 * (M - k)] * sc, g2i = -H[2 * (M - k) + 1] * sc;
+    const double g1r = (double)H[2 * k] * sc, g1i = (double)H[2 * k + 1] * sc;
+    const double g2r = (double)H[2 * (M - k)] * sc, g2i = -(double)H[2 * (M - k) + 1] * sc;
     const double sr = g1r + g2r, si = g1i + g2i, dr = g1r - g2r, di = g1i - g2i;
-    PairEntry e;
-    e.wc = make_float2((float)(2 * sr + 2 * dr * wr), (float)(2 * si + 2 * di * wr));  // c1
-    e.g1 = make_float2((float)(2 * di * wi), (float)(-2 * dr * wi));                    // c2 = -2i d Im(wc')
-    e.g2 = make_float2((float)(2 * sr - 2 * dr * wr), (float)(2 * si - 2 * di * wr));  // c4
+    PairEntry<R> e;
+    e.wc = Vec<R>::m2(2 * sr + 2 * dr * wr, 2 * si + 2 * di * wr);  // c1
+    e.g1 = Vec<R>::m2(2 * di * wi, -2 * dr * wi);                    // c2 = -2i d Im(wc')
+    e.g2 = Vec<R>::m2(2 * sr - 2 * dr * wr, 2 * si - 2 * di * wr);  // c4
     return e;
 }
 
@@ -243,9 +267,10 @@ struct adsp_engine {
     bool generic;  // generic-geometry kernel (chunk not a power of two / F not 2N or 4N)
     char* ring;    // [ring_slots][C][N] samples of cfg.sample_format
     int ring_pos;  // slot of the most recent chunk
-    float4* tw;
-    float4* pair;
-    float2* pair0;
+    void* tw;     // real4 / real2 tables: float for the float kernels, double for ADSP_FORMAT_S16_F64 engines
+    void* pair;
+    void* pair0;
+    bool f64() const { return cfg.sample_format == ADSP_FORMAT_S16_F64; }
     char* zeros;   // 4*chunk_size zero bytes
     bool have_spectrum;
     bool real_spec;  // every Im H == 0: the kernel takes the 3-real-constants-per-pair path
@@ -312,7 +337,7 @@ struct adsp_engine {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;   // recorded, not yet read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_ev;  // recycled event pairs
     size_t plane() const { return (size_t)cfg.n_channels * (size_t)cfg.chunk_size; }                 // samples per chunk batch
-    size_t ssize() const { return cfg.sample_format == ADSP_FORMAT_S16 ? sizeof(short) : sizeof(float); }  // bytes per sample
+    size_t ssize() const { return cfg.sample_format == ADSP_FORMAT_F32 ? sizeof(float) : sizeof(short); }  // bytes per sample
     size_t plane_bytes() const { return plane() * ssize(); }
 };
 
@@ -326,13 +351,17 @@ int set_device(const adsp_engine* e) {
 // async = false: blocking copies (the caller has drained the device: nothing is reading the tables).
 // async = true : the tables are staged in pinned memory and copied ON `stream`, i.e. after every launch already queued
 //                there and before every later one - no device-wide synchronisation, the filter changes between two steps.
-int upload_pairs(adsp_engine* e, const float* H, hipStream_t stream, bool async = false) {
+template <class R, class HT>
+int upload_pairs_t(adsp_engine* e, const HT* H, hipStream_t stream, bool async) {
+    using V = Vec<R>;
+    using T2 = typename V::T2;
+    using T4 = typename V::T4;
     const PlanInfo& pl = *e->plan;
     const int M = e->M, T = pl.T;
-    const int R = pl.rad[pl.NP - 1];         // radix of the paired passes: P for XL plans, P/2, P/4 .. otherwise
-    const int D = M / R;                     // bin spacing between a butterfly's outputs
-    const int PU = pl.XL ? 1 : pl.P / R / 2; // pairs of butterflies per thread (in-register plans: (u*T + t, its mirror))
-    const int npairs = pl.XL ? R / 2 : R;    // pair ops per regular thread and pair of butterflies
+    const int RR = pl.rad[pl.NP - 1];        // radix of the paired passes: P for XL plans, P/2, P/4 .. otherwise
+    const int D = M / RR;                     // bin spacing between a butterfly's outputs
+    const int PU = pl.XL ? 1 : pl.P / RR / 2; // pairs of butterflies per thread (in-register plans: (u*T + t, its mirror))
+    const int npairs = pl.XL ? RR / 2 : RR;    // pair ops per regular thread and pair of butterflies
     auto first_bin = [&](int t, int u) {     // the butterfly whose outputs thread t pairs (k = bin + D*r)
         if (!pl.XL) return u * T + t;
         const int lo = 32 * (t >> 6) + (t & 31);
@@ -341,53 +370,57 @@ int upload_pairs(adsp_engine* e, const float* H, hipStream_t stream, bool async 
     auto self_paired = [&](int t, int u) { return (t == 0 && u == 0) || (pl.XL && t == 32); };  // served by tab0
     // A real spectrum (zero-phase kernel) makes c1, c4 real and c2 imaginary: 3 floats per pair instead of 6.
     bool real_spec = true;
-    for (int k = 0; k <= M && real_spec; ++k) real_spec = H[2 * k + 1] == 0.0f;
+    for (int k = 0; k <= M && real_spec; ++k) real_spec = H[2 * k + 1] == (HT)0;
     if (getenv("ADSP_FORCE_COMPLEX")) real_spec = false;  // tuning: A/B the two spectrum stages on the same filter
     e->real_spec = real_spec;
-    if (e->host_spec.data() != H) e->host_spec.assign(H, H + 2 * (size_t)(M + 1));
+    if constexpr (std::is_same<HT, float>::value) {
+        if (e->host_spec.data() != H) e->host_spec.assign(H, H + 2 * (size_t)(M + 1));
+    } else {
+        e->host_spec.clear();  // (a float64 spectrum is not kept: adsp_bcast_spectrum carries float32 spectra)
+    }
     // float4 layout [u][h][3][T]: (wc,g1) of pair 2h, (g2 of 2h, wc of 2h+1), (g1,g2) of 2h+1
-    std::vector<float4> tab((size_t)PU * (npairs / 2) * 3 * T, make_float4(0.f, 0.f, 0.f, 0.f));
+    std::vector<T4> tab((size_t)PU * (npairs / 2) * 3 * T, V::m4(0, 0, 0, 0));
     if (real_spec) {
         // [u][g][3][T] float4 = (c1.re, c4.re, c2.im) of pairs 4g .. 4g+3
-        std::vector<float> flat(12);
+        std::vector<double> flat(12);
         for (int u = 0; u < PU; ++u)
             for (int g = 0; g < npairs / 4; ++g)
                 for (int tid = 0; tid < T; ++tid) {
                     if (self_paired(tid, u)) continue;
                     for (int q = 0; q < 4; ++q) {
-                        const PairEntry pe = pair_entry(H, M, first_bin(tid, u) + D * (4 * g + q));
+                        const PairEntry<R> pe = pair_entry<R>(H, M, first_bin(tid, u) + D * (4 * g + q));
                         flat[3 * q + 0] = pe.wc.x;
                         flat[3 * q + 1] = pe.g2.x;
                         flat[3 * q + 2] = pe.g1.y;
                     }
                     for (int j = 0; j < 3; ++j)
                         tab[((size_t)(u * (npairs / 4) + g) * 3 + j) * T + tid] =
-                            make_float4(flat[4 * j], flat[4 * j + 1], flat[4 * j + 2], flat[4 * j + 3]);
+                            V::m4(flat[4 * j], flat[4 * j + 1], flat[4 * j + 2], flat[4 * j + 3]);
                 }
     }
     for (int u = 0; u < PU && !real_spec; ++u)
         for (int h = 0; h < npairs / 2; ++h)
             for (int tid = 0; tid < T; ++tid) {
                 if (self_paired(tid, u)) continue;  // self-paired butterflies: tab0
-                const PairEntry a = pair_entry(H, M, first_bin(tid, u) + D * (2 * h));
-                const PairEntry b = pair_entry(H, M, first_bin(tid, u) + D * (2 * h + 1));
+                const PairEntry<R> a = pair_entry<R>(H, M, first_bin(tid, u) + D * (2 * h));
+                const PairEntry<R> b = pair_entry<R>(H, M, first_bin(tid, u) + D * (2 * h + 1));
                 const size_t row = (size_t)(u * (npairs / 2) + h) * 3;
-                tab[(row + 0) * T + tid] = make_float4(a.wc.x, a.wc.y, a.g1.x, a.g1.y);
-                tab[(row + 1) * T + tid] = make_float4(a.g2.x, a.g2.y, b.wc.x, b.wc.y);
-                tab[(row + 2) * T + tid] = make_float4(b.g1.x, b.g1.y, b.g2.x, b.g2.y);
+                tab[(row + 0) * T + tid] = V::m4(a.wc.x, a.wc.y, a.g1.x, a.g1.y);
+                tab[(row + 1) * T + tid] = V::m4(a.g2.x, a.g2.y, b.wc.x, b.wc.y);
+                tab[(row + 2) * T + tid] = V::m4(b.g1.x, b.g1.y, b.g2.x, b.g2.y);
             }
-    std::vector<float2> tab0((size_t)(R + 1) * 3);
+    std::vector<T2> tab0((size_t)(RR + 1) * 3);
     auto put0 = [&](int idx, int k) {
-        const PairEntry pe = pair_entry(H, M, k);
+        const PairEntry<R> pe = pair_entry<R>(H, M, k);
         tab0[idx * 3 + 0] = pe.wc;
         tab0[idx * 3 + 1] = pe.g1;
         tab0[idx * 3 + 2] = pe.g2;
     };
     put0(0, 0);
     put0(1, M / 2);
-    for (int r = 1; r < R / 2; ++r) put0(2 + (r - 1), D * r);
-    for (int r = 0; r < R / 2; ++r) put0(2 + (R / 2 - 1) + r, D / 2 + D * r);
-    const size_t b1 = tab.size() * sizeof(float4), b0 = tab0.size() * sizeof(float2);
+    for (int r = 1; r < RR / 2; ++r) put0(2 + (r - 1), D * r);
+    for (int r = 0; r < RR / 2; ++r) put0(2 + (RR / 2 - 1) + r, D / 2 + D * r);
+    const size_t b1 = tab.size() * sizeof(T4), b0 = tab0.size() * sizeof(T2);
     if (async) {
         if (e->pin_tab_bytes < b1 + b0) {  // first use (the table size of an engine never changes afterwards)
             for (int i = 0; i < 2; ++i) {
@@ -412,6 +445,15 @@ int upload_pairs(adsp_engine* e, const float* H, hipStream_t stream, bool async 
     }
     e->have_spectrum = true;
     return ADSP_OK;
+}
+
+// float32 or float64 spectrum into a float or float64 engine (exactly one of H32 / H64 is given)
+int upload_pairs(adsp_engine* e, const float* H32, hipStream_t stream, bool async = false, const double* H64 = nullptr) {
+    if (e->f64()) return H64 ? upload_pairs_t<double, double>(e, H64, stream, async) : upload_pairs_t<double, float>(e, H32, stream, async);
+    if (!H64) return upload_pairs_t<float, float>(e, H32, stream, async);
+    std::vector<float> h(2 * (size_t)(e->M + 1));
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (float)H64[i];
+    return upload_pairs_t<float, float>(e, h.data(), stream, async);
 }
 
 int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream_t stream, bool resident = false) {
@@ -645,15 +687,16 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     if ((err = hipMalloc(&e->ring, ring_bytes)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc ring (%zu bytes): %s", ring_bytes, hipGetErrorString(err)));
     if ((err = hipMemset(e->ring, 0, ring_bytes)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMemset: %s", hipGetErrorString(err)));
     std::vector<float4> tw;
-    build_twiddles(*pl, tw);
-    if ((int)tw.size() != pl->tw_total) return bail(fail(ADSP_ERR_STATE, "internal: twiddle count %zu != %d", tw.size(), pl->tw_total));
-    const size_t tw_bytes = (tw.size() + 1) * sizeof(float4);
-    if ((err = hipMalloc(&e->tw, tw_bytes)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
-    if (!tw.empty() && (err = hipMemcpy(e->tw, tw.data(), tw.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess)
+    std::vector<double4> tw64;
+    if (e->f64()) build_twiddles<double>(*pl, tw64); else build_twiddles<float>(*pl, tw);
+    const size_t tw_n = e->f64() ? tw64.size() : tw.size(), t4 = e->f64() ? sizeof(double4) : sizeof(float4);
+    if ((int)tw_n != pl->tw_total) return bail(fail(ADSP_ERR_STATE, "internal: twiddle count %zu != %d", tw_n, pl->tw_total));
+    if ((err = hipMalloc(&e->tw, (tw_n + 1) * t4)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
+    if (tw_n && (err = hipMemcpy(e->tw, e->f64() ? (const void*)tw64.data() : (const void*)tw.data(), tw_n * t4, hipMemcpyHostToDevice)) != hipSuccess)
         return bail(fail(ADSP_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(err)));
     const int R = pl->rad[pl->NP - 1];  // radix of the paired passes
-    if ((err = hipMalloc(&e->pair, (size_t)(pl->P / 2) * 3 * pl->T * sizeof(float4))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
-    if ((err = hipMalloc(&e->pair0, (size_t)(R + 1) * 3 * sizeof(float2))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
+    if ((err = hipMalloc(&e->pair, (size_t)(pl->P / 2) * 3 * pl->T * t4)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
+    if ((err = hipMalloc(&e->pair0, (size_t)(R + 1) * 3 * (t4 / 2))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
     if ((err = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(err)));
     if ((err = hipEventCreateWithFlags(&e->ev_in_ready, hipEventDisableTiming)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(err)));
     if ((err = hipEventCreateWithFlags(&e->ev_copy_done, hipEventDisableTiming)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(err)));
@@ -712,6 +755,16 @@ int adsp_set_spectrum(adsp_engine* e, const float* spectrum, int n_bins) {
     return upload_pairs(e, spectrum, nullptr);
 }
 
+int adsp_set_spectrum_f64(adsp_engine* e, const double* spectrum, int n_bins) {
+    if (!e || !spectrum) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (n_bins != e->M + 1) return fail(ADSP_ERR_ARG, "n_bins %d != fft_size/2+1 = %d", n_bins, e->M + 1);
+    int rc = set_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    e->kernel_reach = -1;
+    return upload_pairs(e, nullptr, nullptr, false, spectrum);
+}
+
 int adsp_set_spectrum_async(adsp_engine* e, const float* spectrum, int n_bins, void* stream) {
     if (!e || !spectrum) return fail(ADSP_ERR_ARG, "NULL argument");
     if (n_bins != e->M + 1) return fail(ADSP_ERR_ARG, "n_bins %d != fft_size/2+1 = %d", n_bins, e->M + 1);
@@ -748,6 +801,7 @@ int adsp_bcast_spectrum(adsp_engine* const* engines, int n, int root) {
     }
     const adsp_engine* r = engines[root];
     if (!r->have_spectrum) return fail(ADSP_ERR_STATE, "the root engine has no spectrum yet (adsp_set_spectrum)");
+    if (r->host_spec.empty()) return fail(ADSP_ERR_STATE, "the root engine's spectrum was given in float64 (adsp_set_spectrum_f64): broadcasts carry float32 spectra");
     for (int i = 0; i < n; ++i) {
         // a spectrum only means something together with the window geometry it was designed for
         const adsp_config &a = engines[i]->cfg, &b = r->cfg;

@@ -19,47 +19,12 @@ struct PlanInfo {
     hipError_t (*prepare_generic)();
 };
 
-template <class PL, int CPB>
-constexpr int lds_bytes() {
-#if ADSP_ABLATE & 1024
-    if (PL::M == 4096) return 32000;
+#include "plan_table_core.inc"
+#ifdef ADSP_WITH_F64
+namespace f64 {
+#include "plan_table_core.inc"
+}  // namespace f64
 #endif
-#if ADSP_ABLATE & 4096
-    if (PL::M == 4096) return 44 * 1024;  // tuning: three workgroups per CU instead of four
-#endif
-    return PL::LDS_ELEMS * CPB * (int)sizeof(float2);
-}
-
-template <class PL, int CPB, int FQ, bool S16, bool EPI>
-hipError_t launch_impl(const KernelArgs& a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((fftconv_kernel<PL, CPB, FQ, S16, EPI>), dim3(grid), dim3(PL::T * CPB), (lds_bytes<PL, CPB>()), s, a);
-    return hipGetLastError();
-}
-
-template <class PL, int CPB, int FQ, bool S16, bool EPI>
-hipError_t prepare_impl() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fftconv_kernel<PL, CPB, FQ, S16, EPI>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<PL, CPB>());
-}
-
-template <class PL, int CPB, bool S16, bool EPI>
-hipError_t launch_generic_impl(const KernelArgs& a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((fftconv_generic_kernel<PL, CPB, S16, EPI>), dim3(grid), dim3(PL::T * CPB), (lds_bytes<PL, CPB>()), s, a);
-    return hipGetLastError();
-}
-
-template <class PL, int CPB, bool S16, bool EPI>
-hipError_t prepare_generic_impl() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fftconv_generic_kernel<PL, CPB, S16, EPI>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<PL, CPB>());
-}
-
-template <class PL, int CPB, int FQ, bool S16, bool EPI>
-constexpr PlanInfo make_plan() {
-    return PlanInfo{PL::M, FQ, PL::P, PL::T, CPB, PL::NP, PL::XL ? 1 : 0, {PL::fwd(0), PL::fwd(1), PL::fwd(2), PL::fwd(3)},
-                    PL::tw_total, lds_bytes<PL, CPB>(), &launch_impl<PL, CPB, FQ, S16, EPI>, &prepare_impl<PL, CPB, FQ, S16, EPI>,
-                    &launch_generic_impl<PL, CPB, S16, EPI>, &prepare_generic_impl<PL, CPB, S16, EPI>};
-}
 
 // M (complex points) x FQ (= 4 F/N, the transform length in quarter chunks) -> plan.  Radices forward (inverse = reversed); last forward radix is P/2
 // (in-register pairing) or P (XL, cross-lane pairing) - see fftconv_kernel.hpp.
@@ -105,5 +70,6 @@ const PlanInfo* plans_f32(int* count);
 const PlanInfo* plans_s16(int* count);
 const PlanInfo* plans_f32_epi(int* count);  // same list, kernels with the fused output effect (float32 only)
 const PlanInfo* variants_f32(int* count);  // A/B alternatives, ADSP_PLAN_VARIANT=<n>
+const PlanInfo* plans_s16_f64(int* count);  // int16 samples, float64 arithmetic (namespace adsp::f64 kernels): plans_s16_f64.hip
 
 }  // namespace adsp

@@ -264,8 +264,9 @@ def partition(fir: FirStream, max_taps: int = 14336):
     return parts
 
 
-def engine_spectrum(fir: FirStream, geo: Geometry, gain: float = 1.0) -> np.ndarray:
-    """rfft of the (shift-delayed) kernel at F points, float64 -> complex64, as interleaved float32.
+def engine_spectrum(fir: FirStream, geo: Geometry, gain: float = 1.0, dtype=np.float32) -> np.ndarray:
+    """rfft of the (shift-delayed) kernel at F points, float64 -> complex64, as interleaved float32
+    (dtype=np.float64: complex128 as interleaved float64, for the float64 engines).
 
     `gain` scales the kernel; int16 engines fold the reference's two PCM conversions into it (PCM16_GAIN)."""
     padded = np.zeros(geo.fft_size)
@@ -273,4 +274,6 @@ def engine_spectrum(fir: FirStream, geo: Geometry, gain: float = 1.0) -> np.ndar
     spec = np.fft.rfft(padded)
     if geo.zero_phase:
         spec = spec.real + 0j  # circularly even kernel: the imaginary part is round-off, and exact zeros select the real path
+    if dtype == np.float64:
+        return np.ascontiguousarray(spec.astype(np.complex128)).view(np.float64)
     return np.ascontiguousarray(spec.astype(np.complex64)).view(np.float32)

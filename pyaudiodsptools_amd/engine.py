@@ -11,7 +11,8 @@ import numpy as np
 from . import _capi
 from .design import PCM16_GAIN, FirStream, engine_spectrum, fits_one_transform, overlap_save_geometry, partition
 
-_FORMATS = {"f32": (_capi.ADSP_FORMAT_F32, np.float32), "s16": (_capi.ADSP_FORMAT_S16, np.int16)}
+_FORMATS = {"f32": (_capi.ADSP_FORMAT_F32, np.float32), "s16": (_capi.ADSP_FORMAT_S16, np.int16),
+            "s16_f64": (_capi.ADSP_FORMAT_S16_F64, np.int16)}  # int16 samples, float64 arithmetic (the exact-FFT engines)
 
 
 def _ptr(x):
@@ -37,10 +38,11 @@ class FirEngine:
         self.fir = fir
         self.fft_mult = fft_mult if fft_mult != int(fft_mult) else int(fft_mult)
         if sample_format not in _FORMATS:
-            raise ValueError("sample_format must be 'f32' or 's16'")
+            raise ValueError("sample_format must be 'f32', 's16' or 's16_f64'")
         self.sample_format = sample_format
         self._fmt_code, self.dtype = _FORMATS[sample_format]
-        # int16 engines: (float)x in, (int16)trunc(y) out; the reference's /32768 and *32767 live in the spectrum
+        # int16 engines: (float)x in, (int16)trunc(y) out; the reference's /32768 and *32767 live in the spectrum.
+        # float64 int16 engines apply both conversions to the letter inside the kernel: no gain in the spectrum
         self.gain = PCM16_GAIN if sample_format == "s16" else 1.0
         self.optimize_for = optimize_for
         self.geometry = geo = overlap_save_geometry(fir, self.fft_mult, optimize_for)
@@ -79,7 +81,12 @@ class FirEngine:
             raise ValueError("new filter needs a different transform geometry; create a new engine")
         self.fir = fir
         self.spectrum = engine_spectrum(fir, geo, self.gain)
-        if live:
+        if self.sample_format == "s16_f64":
+            if live:
+                raise ValueError("float64 engines change their filter through the set-up path only")
+            spec64 = engine_spectrum(fir, geo, 1.0, np.float64)
+            _capi.check(self._lib.adsp_set_spectrum_f64(self._h, _ptr(spec64), spec64.size // 2))
+        elif live:
             _capi.check(self._lib.adsp_set_spectrum_async(self._h, _ptr(self.spectrum), self.spectrum.size // 2, _ptr(stream)))
         else:
             self.upload_spectrum(self.spectrum)
@@ -149,7 +156,7 @@ class FirEngine:
     # -- apply --------------------------------------------------------------------------------
     def apply_host(self, x):
         """x: host array [steps, C, N] (or [C, N]) of the engine's sample type -> same shape, fresh array."""
-        if self.sample_format == "s16" and np.asarray(x).dtype != np.int16:
+        if self.sample_format != "f32" and np.asarray(x).dtype != np.int16:
             raise TypeError("this engine filters int16 PCM; pass an int16 array")
         x = np.ascontiguousarray(x, dtype=self.dtype)
         squeeze = x.ndim == 2

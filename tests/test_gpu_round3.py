@@ -383,3 +383,75 @@ def test_example1_full_run_through_the_dropin_surface(adsp):
     eng = adsp.FirEngine(dev.fir, channels=1, optimize_for="batch")
     y = eng.apply_host(np.stack(chunks)[:, None, :])[:, 0, :].reshape(-1)
     assert np.abs(y[::8] - g["out_dec8"]).max() <= 1e-5 * scale
+
+
+def _int16_mismatch(a, b):
+    d = np.abs(a.astype(np.int32) - b.astype(np.int32))
+    return int(d.max()), int((d > 0).sum()), d.size
+
+
+def test_exact_fft_engine_on_the_reference_wav_fixtures(adsp):
+    """a FAST exact int16 path.  sample_format "s16_f64" runs the same kernels in float64 with the reference's
+    conversions to the letter: on the Example1 / Example2 WAV slices it must equal the float64 direct sum (ExactFirEngine)
+    bit for bit, and differ from the reference's own int16 export no more than the direct sum does (one boundary sample)."""
+    from pyaudiodsptools_amd import ExactFirEngine, FirEngine, FirStream, design
+    n, fs = 4096, 44100
+    fir = FirStream(design.lowcut_kernel(800, fs, n), n)
+    g1 = np.load(os.path.join(ROOT, "tests", "golden", "kat_example1.npz"))
+    g2 = np.load(os.path.join(ROOT, "tests", "golden", "kat_example2.npz"))
+    pcm1 = g1["pcm16_first8"].reshape(8, 1, n)
+    pcm2 = np.ascontiguousarray(g2["pcm16_first4_stereo"].T.reshape(2, 4, n).transpose(1, 0, 2))
+    for pcm, refs in ((pcm1, [g1["out_first8"]]), (pcm2, [g2["out_left"], g2["out_right"]])):
+        for opt in ("batch", "stream"):
+            eng = FirEngine(fir, channels=pcm.shape[1], sample_format="s16_f64", optimize_for=opt)
+            y = eng.apply_host(pcm) if opt == "batch" else np.stack([eng.apply_host(pcm[k]) for k in range(pcm.shape[0])])
+            ex = ExactFirEngine(fir, channels=pcm.shape[1], sample_format="s16")
+            t = ex.apply_host(pcm)
+            assert np.array_equal(y, t), _int16_mismatch(y, t)
+            for c, ref in enumerate(refs):
+                ref16 = (ref * 32767).astype(np.int16)  # Utility.py:306
+                worst, count, size = _int16_mismatch(y[:, c].reshape(-1), ref16)
+                assert worst <= 1 and count <= 1, (worst, count, size)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_exact_fft_engine_random_cases_against_the_direct_sum(adsp, seed):
+    """Random chunk sizes (powers of two and arbitrary multiples of 4: the generic-geometry kernel), filters, channel counts and
+    call patterns in float64: never more than one LSB from the direct sum, and only where the float64 result straddles a
+    float32 rounding boundary (expected about 1e-7 of the samples; the test allows 1e-5)."""
+    import torch
+    from pyaudiodsptools_amd import ExactFirEngine, FirEngine, FirStream, design
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([64, 128, 256, 512, 1024, 2048, 4096, 8192, 1000, 1920, 3000, 20 * 4, 12000]))
+    fs = int(rng.choice([44100, 48000, 96000]))
+    kind = str(rng.choice(["lowcut", "highcut", "eq", "chain", "asym"]))
+    lc = FirStream(design.lowcut_kernel(float(rng.uniform(50, 2000)), fs, n), n)
+    hc = FirStream(design.highcut_kernel(float(rng.uniform(3000, 0.45 * fs)), fs, n), n)
+    eq = FirStream(design.eq3_composite(100, float(rng.uniform(-6, 6)), 700, float(rng.uniform(-6, 6)), 8000, float(rng.uniform(-6, 6)), fs, n), n)
+    if kind == "chain" and n <= 8192:
+        fir = lc.then(eq).then(hc).trimmed()
+    elif kind == "asym":
+        m = int(rng.integers(3, max(4, n // 2)))
+        taps = rng.normal(size=m) * np.hanning(m + 2)[1:-1]
+        fir = FirStream(taps / np.abs(taps).sum(), n, 1, int(rng.integers(0, max(1, n // 4))))
+    else:
+        fir = {"lowcut": lc, "highcut": hc, "eq": eq, "chain": eq}[kind]
+    if not design.fits_one_transform(fir):
+        pytest.skip("kernel longer than one transform")
+    channels, steps = int(rng.choice([1, 2, 5, 17, 64])), int(rng.integers(3, 8))
+    opt = str(rng.choice(["stream", "batch"]))
+    eng = FirEngine(fir, channels=channels, sample_format="s16_f64", optimize_for=opt)
+    x = torch.randint(-32768, 32768, (steps, channels, n), device="cuda", dtype=torch.int16, generator=torch.Generator(device="cuda").manual_seed(seed))
+    y = torch.zeros_like(x)
+    s = torch.cuda.current_stream().cuda_stream
+    if rng.random() < 0.5:
+        eng.apply_device(x, y, steps, s)
+    else:
+        for k in range(steps):
+            eng.apply_device(x[k], y[k], 1, s)
+    ex = ExactFirEngine(fir, channels=channels, sample_format="s16")
+    t = torch.zeros_like(x)
+    ex.apply_device(x, t, steps, s)
+    torch.cuda.synchronize()
+    worst, count, size = _int16_mismatch(y.cpu().numpy(), t.cpu().numpy())
+    assert worst <= 1 and count <= max(1, int(1e-5 * size)), f"N={n} {kind} F={eng.geometry.fft_size} {opt}: {count} of {size} differ, worst {worst}"
