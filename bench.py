@@ -104,7 +104,7 @@ def kernel_sha16():
     """Identity of the kernel sources a PMC traffic figure belongs to (profiles/traffic.json is stamped with it)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("fftconv_kernel.hpp", "plan_table.hpp"):
+    for f in ("fftconv_kernel.hpp", "fftconv_core.inc", "plan_table.hpp", "plan_table_core.inc"):
         h.update(open(os.path.join(ROOT, "pyaudiodsptools_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

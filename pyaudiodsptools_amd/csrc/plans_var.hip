@@ -22,6 +22,9 @@ const PlanInfo kVariants[] = {
     make_plan<Plan<8192, 32, 3, 32, 16, 16, 1, false, true, 3>, 1, 16, false, false>(),   // 12: same, F = 4N (four: +3 %)
     make_plan<Plan<16384, 32, 3, 32, 32, 16, 1, false, true, 4>, 1, 16, false, false>(),  // 13: M = 16384 with 32 points per thread in 512 threads, half exchange: two workgroups of eight waves per CU at 128 VGPRs (48 B of scratch)
     make_plan<Plan<3072, 48, 3, 16, 16, 12, 1, false, true, 3>, 1, 6, false, false>(),    // 14: the 3 * 2^k plan at three waves per SIMD (168 VGPRs, 100 B of scratch)
+    make_plan<Plan<3072, 24, 4, 8, 8, 4, 12, false, false, 4>, 1, 6, false, false>(),     // 15: M = 3072 with 24 points per thread in TWO waves, four passes 8 x 8 x 4 x 12, full exchange (24 KiB: six transforms per CU)
+    make_plan<Plan<3072, 24, 4, 8, 8, 4, 12, false, true, 4>, 1, 6, false, false>(),      // 16: same, half exchange (12 KiB: eight transforms per CU, four waves per SIMD)
+    make_plan<Plan<3072, 24, 4, 8, 8, 4, 12, false, true, 4>, 2, 6, false, false>(),      // 17: same, two transforms per 256-thread workgroup
 };
 // also measured and dropped: M = 8192 at four workgroups per CU / 128 VGPRs (spills, = 5), 64 points per thread for M = 8192
 // (-3 % against 5), M = 8192 with radix-16 paired passes (-7 %), one wave per transform with 8 points per thread for M = 512

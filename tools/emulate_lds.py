@@ -103,4 +103,6 @@ def check(M, P, fwd, half):
 
 
 check(3072, 48, [16, 16, 12], True)
+check(3072, 24, [8, 8, 4, 12], False)
+check(3072, 24, [8, 8, 4, 12], True)
 check(4096, 16, [16, 16, 16], False)
