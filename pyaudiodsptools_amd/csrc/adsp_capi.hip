@@ -475,7 +475,9 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
     a.n_steps = n_steps;
     a.V = ((n_steps == 1 || resident) && !e->generic) ? c.chunk_size : e->block_outputs;
     a.in_ring = resident ? 1 : 0;
-    a.step_tile = (resident && e->lead >= n_steps) ? 4 : 1;
+    // every step already published: nothing will wait, so the launch may run in the multi-step order (a channel group's steps
+    // are neighbours in the grid: their window overlap is an L2 hit); otherwise strictly step-major
+    a.step_tile = (resident && e->lead >= n_steps) ? n_steps : 1;
     a.seq = resident ? e->d_seq : nullptr;
     a.seq_base = e->pub_count - (unsigned)e->lead;  // (wraps like the word itself)
     a.seq_fail = resident ? e->d_seq + 1 : nullptr;
@@ -506,7 +508,7 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
     a.lookback = c.lookback;
     a.j0 = c.out_offset;
     a.ncg = (c.n_channels + pl.CPB - 1) / pl.CPB;
-    const long long grid = (long long)((a.ncg + 7) / 8) * 8 * (resident ? (a.nblk + 3) / 4 * 4 : a.nblk);  // resident: whole tiles of 4 steps
+    const long long grid = (long long)((a.ncg + 7) / 8) * 8 * (resident ? (a.nblk + a.step_tile - 1) / a.step_tile * a.step_tile : a.nblk);  // resident: whole step tiles
     if (grid > 0x7fffffffLL) return fail(ADSP_ERR_ARG, "launch too large (%lld workgroups)", grid);
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     if (e->timing) {

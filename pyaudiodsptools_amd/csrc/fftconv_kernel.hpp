@@ -97,7 +97,7 @@ struct KernelArgs {
     // resident ring launches (adsp_apply_ring_resident): the new chunks are ring slots too (`in` is unused) and block b may
     // only start once the producer has PUBLISHED step b - the 32-bit sequence word has reached seq_base + b + 1
     int in_ring;                   // chunks q >= 0 are ring slots (ring_pos + 1 + q) mod ring_slots
-    int step_tile;                 // 1 or 4: steps per tile of the step-major workgroup order
+    int step_tile;                 // steps per tile of the step-major workgroup order (1, or n_steps when all are published)
     const unsigned* seq;           // device sequence word the producer side bumps after filling a slot (nullptr: no waiting)
     unsigned seq_base;             // value of the word when every step before this launch had been published
     unsigned* seq_fail;            // set to 1 by a workgroup that gave up waiting (its block's outputs are then not written)
