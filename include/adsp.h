@@ -264,7 +264,7 @@ ADSP_API int adsp_apply_ring(adsp_engine* engine, void* d_out, void* stream);
  *   MI355X / ROCm 7.2 the producer stream's commands - the runtime's own write of the sequence word included - then do not
  *   get through either: the launch ends by time-out.  Launch the consumer before its input only with grids the GPU can hold
  *   (the -m gpu test: 20 workgroups per step); at full size publish first - the launch then never waits and runs at the
- *   multi-step rate (config 3: 5.5-5.8 us per step against 8.0 for one launch per step).
+ *   multi-step rate (config 3: 5.5-6.1 us per step against 8.0 for one launch per step).
  *   Use explicitly created streams for both sides: work on the legacy default (NULL) stream is implicitly ordered against
  *   every blocking stream, so a producer would wait for the very launch that waits for it.
  *   Resident and per-step ring calls do not mix: adsp_ring_reset_order (a drain) switches between them.
