@@ -103,9 +103,12 @@ def parse(argv=None):
 def kernel_sha16():
     """Identity of the kernel sources a PMC traffic figure belongs to (profiles/traffic.json is stamped with it)."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for f in ("fftconv_kernel.hpp", "fftconv_core.inc", "plan_table.hpp", "plan_table_core.inc"):
-        h.update(open(os.path.join(ROOT, "pyaudiodsptools_amd", "csrc", f), "rb").read())
+        src = open(os.path.join(ROOT, "pyaudiodsptools_amd", "csrc", f), "r").read()
+        src = re.sub(r"//[^\n]*", "", src)          # the code, not its comments: a reworded remark does not stale a measurement
+        h.update(" ".join(src.split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -35,6 +35,11 @@
 //  * no packed f32 math (half rate on gfx950), no MFMA (no contraction): ~100 flop/sample against
 //    8-10 B/sample; sustained multi-step launches run at 1.9-2.0 GHz (power controller), single-step launches at
 //    2.5-2.6 GHz (the chip idles between them) - DESIGN.md section 5.
+//  * round 3: the kernels themselves live in fftconv_core.inc, written against `real` and included here once for float
+//    (namespace adsp) and, under ADSP_WITH_F64, once for double (namespace adsp::f64: the exact-FFT int16 engines); the
+//    geometry parameter is FQ = 4F/N (8, 16, or 6 for the 3 * 2^k plan); the spectrum stage is three sequential ifs
+//    (an if / else chain doubled the register pressure: DESIGN.md section 3.1); resident ring launches wait per step on a
+//    sequence word (wait_for_step).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
