@@ -25,6 +25,10 @@ const PlanInfo kVariants[] = {
     make_plan<Plan<3072, 24, 4, 8, 8, 4, 12, false, false, 4>, 1, 6, false, false>(),     // 15: M = 3072 with 24 points per thread in TWO waves, four passes 8 x 8 x 4 x 12, full exchange (24 KiB: six transforms per CU)
     make_plan<Plan<3072, 24, 4, 8, 8, 4, 12, false, true, 4>, 1, 6, false, false>(),      // 16: same, half exchange (12 KiB: eight transforms per CU, four waves per SIMD)
     make_plan<Plan<3072, 24, 4, 8, 8, 4, 12, false, true, 4>, 2, 6, false, false>(),      // 17: same, two transforms per 256-thread workgroup
+    make_plan<Plan<512, 16, 3, 8, 8, 8, 1>, 2, 8, false, false>(),                        // 18: config 3's transform as 8 x 8 x 8 (resident launches: 5.96 - 6.01 us per step against 5.49 - 5.72 for the default)
+    make_plan<Plan<512, 16, 3, 8, 8, 8, 1>, 4, 8, false, false>(),                        // 19: same, four transforms per workgroup (6.21 - 6.25)
+    make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 4, 8, false, false>(),                       // 20: the default radices, four transforms per 128-thread workgroup (5.72 - 5.76)
+    make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 1, 8, false, false>(),                       // 21: one transform per 32-thread workgroup (9.65)
 };
 // also measured and dropped: M = 8192 at four workgroups per CU / 128 VGPRs (spills, = 5), 64 points per thread for M = 8192
 // (-3 % against 5), M = 8192 with radix-16 paired passes (-7 %), one wave per transform with 8 points per thread for M = 512
