@@ -100,13 +100,14 @@ def parse(argv=None):
     return a
 
 
-def kernel_sha16():
+def kernel_sha16(csrc=None):
     """Identity of the kernel sources a PMC traffic figure belongs to (profiles/traffic.json is stamped with it)."""
+    csrc = csrc or os.path.join(ROOT, "pyaudiodsptools_amd", "csrc")
     import hashlib
     import re
     h = hashlib.sha256()
     for f in ("fftconv_kernel.hpp", "fftconv_core.inc", "plan_table.hpp", "plan_table_core.inc"):
-        src = open(os.path.join(ROOT, "pyaudiodsptools_amd", "csrc", f), "r").read()
+        src = open(os.path.join(csrc, f), "r").read()
         src = re.sub(r"//[^\n]*", "", src)          # the code, not its comments: a reworded remark does not stale a measurement
         h.update(" ".join(src.split()).encode())
     return h.hexdigest()[:16]

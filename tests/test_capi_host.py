@@ -291,3 +291,26 @@ def test_plain_c_program_links_against_the_abi_and_fails_loudly_without_a_gpu(tm
         pytest.skip("a GPU is visible: the run itself is tests/test_gpu_parity.py::test_plain_c_program_through_the_abi")
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 2 and "adsp_create" in out.stderr and "no HIP device" in out.stderr
+
+
+def test_traffic_stamp_follows_the_kernel_code_not_its_comments(tmp_path):
+    """profiles/traffic.json entries are stamped with bench.kernel_sha16(); bench.py reports `traffic: null` when the stamp
+    differs from the sources it runs on.  The identity must change with the code and must not change with a comment."""
+    import json
+    import shutil
+    import bench
+    src = os.path.join(ROOT, "pyaudiodsptools_amd", "csrc")
+    files = ("fftconv_kernel.hpp", "fftconv_core.inc", "plan_table.hpp", "plan_table_core.inc")
+    for f in files:
+        shutil.copy(os.path.join(src, f), tmp_path / f)
+    base = bench.kernel_sha16(str(tmp_path))
+    assert base == bench.kernel_sha16() and len(base) == 16
+    with open(tmp_path / "fftconv_core.inc", "a") as fh:
+        fh.write("\n// a remark\n\n")
+    assert bench.kernel_sha16(str(tmp_path)) == base
+    with open(tmp_path / "fftconv_core.inc", "a") as fh:
+        fh.write("static const int changed = 1;\n")
+    assert bench.kernel_sha16(str(tmp_path)) != base
+    traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    stamped = [k for k, v in traffic.items() if isinstance(v, dict) and "kernel_sha16" in v]
+    assert "lowcut_4096x4096_batch" in stamped and all(len(traffic[k]["kernel_sha16"]) == 16 for k in stamped)
