@@ -116,3 +116,63 @@ class ShardedFirBank:
         else:
             # gloo / no process group: `self.spectrum` is the host copy taken after the collective completed
             self.engine.upload_spectrum(self.spectrum, reach=max(0, -geo.shift))
+
+
+class LocalFirBank:
+    """All channels of a job on the GPUs of ONE process: contiguous channel shards, one engine per device, one host thread per
+    device, and the filter shared by `adsp_bcast_spectrum` - the RCCL broadcast inside libadsp (ncclCommInitAll: no torchrun,
+    no torch.distributed).  The torchrun counterpart is ShardedFirBank.
+
+    devices: list of HIP device ordinals (default: every visible GPU).  `engine_factory` / `broadcast` exist for the CPU
+    tests (stand-ins for FirEngine / engine.broadcast_filter)."""
+
+    def __init__(self, fir, total_channels, devices=None, ring_slots=0, fft_mult=0, sample_format="f32", optimize_for="stream",
+                 engine_factory=None, broadcast=None):
+        from concurrent.futures import ThreadPoolExecutor
+        if devices is None:
+            from . import _capi
+            devices = list(range(max(1, _capi.device_count())))
+        if engine_factory is None:
+            from .engine import FirEngine, broadcast_filter
+            engine_factory, broadcast = FirEngine, (broadcast or broadcast_filter)
+        self.devices = [int(d) for d in devices]
+        self.total_channels = int(total_channels)
+        self.shards = [shard_range(total_channels, len(self.devices), i) for i in range(len(self.devices))]
+        kw = {}
+        if fft_mult:
+            kw["fft_mult"] = fft_mult
+        if sample_format != "f32":
+            kw["sample_format"] = sample_format
+        if optimize_for != "stream":
+            kw["optimize_for"] = optimize_for
+        # engines of devices without channels (more GPUs than channels) are not created
+        self.engines = [engine_factory(fir, channels=hi - lo, device=d, ring_slots=ring_slots, **kw) if hi > lo else None
+                        for d, (lo, hi) in zip(self.devices, self.shards)]
+        live = [e for e in self.engines if e is not None]
+        if broadcast is not None and live:
+            broadcast(live, 0)  # every engine takes over engine 0's filter (bit-identical tables on every GPU)
+        self._pool = ThreadPoolExecutor(max_workers=max(1, len(live)))
+
+    def apply_host(self, x):
+        """x [steps, total_channels, N] (or [total_channels, N]) host array -> same shape; every shard on its own GPU, concurrently."""
+        x = np.asarray(x)
+        squeeze = x.ndim == 2
+        if squeeze:
+            x = x[None]
+        if x.shape[1] != self.total_channels:
+            raise ValueError(f"expected {self.total_channels} channels, got {x.shape[1]}")
+        jobs = [(e, lo, hi) for e, (lo, hi) in zip(self.engines, self.shards) if e is not None]
+        parts = list(self._pool.map(lambda j: j[0].apply_host(np.ascontiguousarray(x[:, j[1]:j[2]])), jobs))
+        out = np.concatenate(parts, axis=1)
+        return out[0] if squeeze else out
+
+    def reset(self):
+        for e in self.engines:
+            if e is not None:
+                e.reset()
+
+    def close(self):
+        self._pool.shutdown(wait=True)
+        for e in self.engines:
+            if e is not None and hasattr(e, "close"):
+                e.close()

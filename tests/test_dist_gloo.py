@@ -93,3 +93,43 @@ def test_two_rank_sharded_filter_matches_oracle(tmp_path, total_channels):
         ref = orc.OracleLowCut(800, 44100, n)
         want = np.concatenate([ref.apply(x[k, c]) for k in range(steps)])
         assert_parity(y[:, c].reshape(-1), want, what=f"channel {c}")
+
+
+def test_local_bank_shards_channels_over_devices_in_one_process():
+    """dist.LocalFirBank (one process, N devices, adsp_bcast_spectrum) with stand-in engines: contiguous balanced shards, the
+    root's filter on every device (device 1 starts from a WRONG filter), more devices than channels."""
+    from pyaudiodsptools_amd import design
+    from pyaudiodsptools_amd.dist import LocalFirBank
+    n, fs, steps = 512, 44100, 4
+    fir = design.FirStream(design.lowcut_kernel(800, fs, n), n)
+    wrong = design.FirStream(design.lowcut_kernel(5000, fs, n), n)
+    made = []
+
+    class Chunked(NumpyEngine):  # [steps, C, N] batches like FirEngine.apply_host
+        def apply_host(self, x):
+            return np.stack([NumpyEngine.apply_host(self, x[k]) for k in range(x.shape[0])])
+
+    def factory(f, channels=1, device=0, ring_slots=0, **kw):
+        mine = wrong if device == 1 else f
+        e = Chunked(mine, channels=channels, device=device)
+        e.upload_spectrum(design.engine_spectrum(mine, design.overlap_save_geometry(mine)))
+        made.append(e)
+        return e
+
+    def broadcast(engines, root):
+        for e in engines:
+            e.spec = engines[root].spec.copy()
+
+    for total, devices in ((7, [0, 1, 2]), (2, [0, 1, 2, 3])):
+        made.clear()
+        bank = LocalFirBank(fir, total, devices=devices, engine_factory=factory, broadcast=broadcast)
+        assert [hi - lo for lo, hi in bank.shards] == ([3, 2, 2] if total == 7 else [1, 1, 0, 0])
+        assert sum(e is not None for e in bank.engines) == min(total, len(devices))
+        x = np.random.default_rng(total).uniform(-1, 1, (steps, total, n)).astype(np.float32)
+        y = bank.apply_host(x)
+        from oracle import fftfilter_oracle as o
+        taps = o.lowcut_taps(800, fs, n)
+        for c in range(total):
+            ref = o.direct_stream_convolution(taps, x[:, c].reshape(-1), n)
+            assert np.abs(y[:, c].reshape(-1) - ref).max() <= 1e-5 * np.abs(ref).max()
+        bank.close()

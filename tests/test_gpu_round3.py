@@ -455,3 +455,18 @@ def test_exact_fft_engine_random_cases_against_the_direct_sum(adsp, seed):
     torch.cuda.synchronize()
     worst, count, size = _int16_mismatch(y.cpu().numpy(), t.cpu().numpy())
     assert worst <= 1 and count <= max(1, int(1e-5 * size)), f"N={n} {kind} F={eng.geometry.fft_size} {opt}: {count} of {size} differ, worst {worst}"
+
+
+def test_local_bank_one_process_real_engines(adsp):
+    """dist.LocalFirBank on the GPUs of this process (one here): channel shards, adsp_bcast_spectrum, concurrent apply."""
+    from pyaudiodsptools_amd import FirStream, design
+    from pyaudiodsptools_amd.dist import LocalFirBank
+    n, fs, channels, steps = 1024, 44100, 11, 5
+    fir = FirStream(design.eq3_composite(100, 2, 700, -4, 8000, 5, fs, n), n)
+    bank = LocalFirBank(fir, channels, devices=[0])
+    x = np.random.default_rng(2).uniform(-1, 1, (steps, channels, n)).astype(np.float32)
+    y = bank.apply_host(x)
+    ex = adsp.ExactFirEngine(fir, channels=channels)
+    t = ex.apply_host(x)
+    assert np.abs(y - t).max() <= 1e-5 * np.abs(t).max()
+    bank.close()
