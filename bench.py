@@ -52,7 +52,9 @@ FILTER_NAMES = {"lowcut": "CreateLowCutFilter(800)", "highcut": "CreateHighCutFi
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16, help="timed steps; a step = one launch over one resident batch (see module doc)")
+    ap.add_argument("--steps", type=int, default=64, help="timed steps PER RUN; a step = one launch over one resident batch (see module doc)")
+    ap.add_argument("--runs", type=int, default=5, help="the timed region (K steps between two barriers) is repeated this many times on the same "
+                    "resident batches; `value` is the MEDIAN run (SURVEY 8d), every run is listed under \"runs\"")
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed run of the same workload before the W warmup steps, until this much wall time has passed: "
@@ -76,6 +78,8 @@ def parse(argv=None):
     ap.add_argument("--effect", default="none", choices=["none", "softclip", "harddist", "saturator", "volume", "tremolo"],
                     help="fuse a stateless wave-shaper on the kernel's output (not part of the headline workload)")
     ap.add_argument("--trim", type=float, default=-1.0, help="chain only: end-tap trimming (FirStream.trimmed); -1 = library default, 0 = off")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the post-timing parity self-check of the timed output (tuning runs only: "
+                    "the line then says parity_checked false)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stream-extra", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
@@ -236,9 +240,14 @@ class Runner:
             self.ins = [synth((cps, C, N)) for _ in range(n_in)]
             self.outs = [torch.empty((cps, C, N), device=dev, dtype=dt) for _ in range(2)]
 
+            self.n_in = n_in
+            self.step_count = 0  # launches so far: launch j reads ins[j % n_in] (history: the tail of ins[(j - 1) % n_in]) and writes outs[j % 2]
+
             def run(k_steps):
-                for i in range(k_steps):
-                    eng.apply_device(self.ins[i % n_in], self.outs[i % 2], cps, sptr)
+                j0 = self.step_count
+                for j in range(j0, j0 + k_steps):
+                    eng.apply_device(self.ins[j % n_in], self.outs[j % 2], cps, sptr)
+                self.step_count = j0 + k_steps
             self.run = run
 
     def _try_graph(self, steps_per_replay):
@@ -276,7 +285,10 @@ class Runner:
             except Exception:
                 pass
 
-    def measure(self, steps, warm, barrier=None, prewarm_ms=0.0, time_kernels=True, graph=False):
+    def measure(self, steps, warm, barrier=None, prewarm_ms=0.0, time_kernels=True, graph=False, repeats=1, clock=False):
+        """W untimed warm-up steps, then `repeats` timed regions of exactly `steps` steps each, every one bracketed by a
+        barrier + synchronize on both sides.  Returns (steps, warm, wall, kern_ms, launches) of the MEDIAN run; all runs are
+        kept in self.last_runs as (wall_s, kernel_ms, launches, shader_mhz)."""
         torch, eng = self.torch, self.eng
         run = self.run_graph if graph else self.run
         steps = max(1, steps)
@@ -288,22 +300,80 @@ class Runner:
         if warm:
             run(warm)
         torch.cuda.synchronize()
-        if barrier:
-            barrier()
-        torch.cuda.synchronize()
-        eng.enable_kernel_timing(time_kernels and not graph)
-        t0 = time.perf_counter()
-        run(steps)
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
-        if barrier:
-            barrier()
-        torch.cuda.synchronize()
-        kern_ms, launches = eng.kernel_time()
-        eng.enable_kernel_timing(False)
+        runs = []
+        probe_stream = None
+        if clock:
+            try:
+                from pyaudiodsptools_amd.engine import ClockProbe
+                probe_stream = torch.cuda.Stream()
+            except Exception:
+                probe_stream = None
+        for _ in range(max(1, repeats)):
+            if barrier:
+                barrier()
+            torch.cuda.synchronize()
+            eng.enable_kernel_timing(time_kernels and not graph)
+            t0 = time.perf_counter()
+            run(steps)
+            probe = None
+            if probe_stream is not None:
+                try:  # one lane on a side stream, beside the queued launches: shader cycles over 10 ms of the 100 MHz clock
+                    probe = ClockProbe(torch.cuda.current_device(), 10000.0, probe_stream.cuda_stream)
+                except Exception:
+                    probe = None
+            torch.cuda.current_stream().synchronize()
+            wall = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            if barrier:
+                barrier()
+            torch.cuda.synchronize()
+            kern_ms, launches = eng.kernel_time()
+            eng.enable_kernel_timing(False)
+            mhz = None
+            if probe is not None:
+                try:
+                    mhz = probe.read()
+                except Exception:
+                    mhz = None
+            runs.append((wall, kern_ms, launches, mhz))
+        self.last_runs = runs
         chk = self.outs[0].reshape(-1)[:: max(1, self.outs[0].numel() // 65536)].float()
         assert bool(torch.isfinite(chk).all()) and (float(chk.abs().max()) > 0 or os.environ.get("ADSP_BENCH_AMPLITUDE") == "0")
+        med = sorted(range(len(runs)), key=lambda i: runs[i][0])[len(runs) // 2]
+        self.median_run = med
+        wall, kern_ms, launches, _ = runs[med]
         return steps, warm, wall, kern_ms, launches
+
+    def parity_check(self, fir, n_channels=32):
+        """What the timed region produced, checked: the output batch of the LAST timed launch, for `n_channels` channels (the
+        first and last eight - first and last workgroups, every XCD residue - and sixteen spread over the rest), every
+        sample against the float64 direct sum of the same FIR computed on the GPU by the exact engine (adsp_exact_*, pinned
+        to the oracle by tests/test_gpu_pcm16.py).  The launch's history is the tail of the batch the launch before it read."""
+        torch = self.torch
+        from pyaudiodsptools_amd import ExactFirEngine
+        if self.mode == "stream" or self.step_count < 2:
+            return None
+        j = self.step_count - 1
+        x, prev, y = self.ins[j % self.n_in], self.ins[(j - 1) % self.n_in], self.outs[j % 2]
+        C, N, cps = self.C, self.N, self.cps
+        k = min(n_channels, C)
+        rng = np.random.default_rng(C)
+        mid = sorted(int(c) for c in rng.choice(np.arange(8, max(9, C - 8)), max(0, k - 16), replace=False)) if C > 16 + (k - 16) else []
+        chans = sorted(set(list(range(min(8, C))) + mid + list(range(max(0, C - 8), C))))
+        idx = torch.tensor(chans, device=x.device)
+        hist = self.eng.geometry.history_chunks
+        xin = torch.cat([prev[cps - hist:].index_select(1, idx), x.index_select(1, idx)], 0).contiguous()
+        ex = ExactFirEngine(fir, channels=len(chans), device=x.device.index, sample_format="f32" if x.dtype == torch.float32 else "s16")
+        truth = torch.empty_like(xin)
+        ex.apply_device(xin, truth, xin.shape[0], torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        truth = truth[hist:].float()
+        got = y.index_select(1, idx).float()
+        scale = float(truth.abs().max())
+        err = float((got - truth).abs().max())
+        ex.close()
+        return {"max_rel_err": err / max(scale, 1e-30), "max_abs_err": err, "scale": scale, "channels": len(chans), "samples": int(got.numel()),
+                "launch": j, "against": "adsp_exact_* float64 direct sum on the same input batch (history = tail of the previous batch)"}
 
 
 def stream_figures(args, fir, dev, local_rank, world, rank, alg_bytes, channels=None, chunk=None, steps=2048):
@@ -436,6 +506,44 @@ def numpy_api_latency(n=4096, reps=1500):
     return (time.perf_counter() - t0) / reps * 1e6
 
 
+def reexec_under_launcher(args):
+    """`python3 bench.py --gpus N` with no launcher around it: bench.py becomes its own launcher - it replaces itself by
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> bench.py
+    <same arguments>`, i.e. exactly the command the driver uses for N > 1 (one process per GPU, RCCL through
+    torch.distributed).  --single-process is the other launcher-free mode (one process, one thread per GPU,
+    adsp_bcast_spectrum)."""
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env["ADSP_BENCH_REEXEC"] = "1"
+    if env.get("ADSP_BENCH_SINGLE_DEVICE") == "1":
+        env.setdefault("ADSP_BENCH_BACKEND", "gloo")  # (test hook: RCCL refuses two ranks on one device)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execvpe(sys.executable, cmd, env)
+
+
+def summarize_runs(runs, samples_per_step_job, steps):
+    """runs: [(wall_s, kernel_ms, launches, shader_mhz)] already reduced over ranks -> (index of the median run, JSON block)."""
+    order = sorted(range(len(runs)), key=lambda i: runs[i][0])
+    med = order[len(order) // 2]
+    vals = [samples_per_step_job * steps / r[0] / 1e6 for r in runs]
+    block = {"n": len(runs), "statistic": "median", "value_msamples_s": [round(v, 1) for v in vals],
+             "ms_per_step": [round(r[0] * 1e3 / steps, 5) for r in runs],
+             "kernel_us_per_launch": [round(r[1] * 1e3 / max(1, r[2]), 2) for r in runs],
+             "min": round(min(vals), 1), "max": round(max(vals), 1), "median": round(vals[med], 1),
+             "spread_pct": round((max(vals) - min(vals)) / vals[med] * 100, 2),
+             "shader_mhz": [None if r[3] is None else round(r[3], 1) for r in runs],
+             "shader_mhz_note": "one-lane probe kernel on a side stream while the timed launches run: shader cycles (s_memtime) per 10 ms "
+                                "of the constant 100 MHz clock (adsp_clock_probe_*); rank 0's GPU"}
+    return med, block
+
+
 def main():
     args = parse()
     import torch
@@ -447,8 +555,7 @@ def main():
     if args.single_process and world > 1:
         raise SystemExit("--single-process drives every GPU from one process: do not launch it under torchrun")
     if args.gpus > 1 and world == 1 and not args.single_process:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        reexec_under_launcher(args)  # does not return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (pyaudiodsptools_amd has no CPU path)")
     # test hooks (single-GPU boxes): ADSP_BENCH_SINGLE_DEVICE=1 puts every rank on GPU 0, ADSP_BENCH_BACKEND=gloo
@@ -460,69 +567,110 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     barrier = None
+    tdist = None
     if world > 1 or os.environ.get("ADSP_BENCH_FORCE_PG") == "1":  # FORCE_PG: run the RCCL broadcast at world size 1
         adist.init_process_group(backend)
         import torch.distributed as tdist
         barrier = tdist.barrier
+    red_dev = dev if backend == "nccl" else "cpu"
 
     fir = make_fir(args)
     C, N = args.channels, args.chunk
     alg_bytes = ALG_BYTES_PER_SAMPLE if args.io == "f32" else 4
     carrier = None
-    if args.single_process:
-        # ONE process, args.gpus devices: an engine and a host thread per GPU, the filter shared by adsp_bcast_spectrum
-        import threading
-        from pyaudiodsptools_amd.engine import broadcast_filter, rccl_version
-        ndev = args.gpus
-        if torch.cuda.device_count() < ndev:
-            raise SystemExit(f"--single-process --gpus {ndev}: only {torch.cuda.device_count()} devices visible")
-        runners = []
-        for i in range(ndev):
-            torch.cuda.set_device(i)
-            runners.append(Runner(args, args.mode, fir, torch.device("cuda", i), i, 1, i))
-        broadcast_filter([r.eng for r in runners], 0)
-        carrier = f"adsp_bcast_spectrum (RCCL {rccl_version()} inside libadsp, ncclCommInitAll over {ndev} device(s), one process)"
-        gate = threading.Barrier(ndev)
-        results, errors = [None] * ndev, []
+    ndev = args.gpus if args.single_process else 1
+    if args.single_process and torch.cuda.device_count() < ndev:
+        raise SystemExit(f"--single-process --gpus {ndev}: only {torch.cuda.device_count()} devices visible")
 
-        def work(i):
-            try:
+    def measure_everywhere(ax, mode, fir_x, steps, warm, prewarm_ms, repeats, clock):
+        """One configuration on every GPU of the job: torchrun ranks (barrier = the process group's) or, with --single-process,
+        one Runner and one host thread per device (barrier = a thread barrier).  Returns (runner of this rank / device 0,
+        runs reduced with MAX over ranks, parity block reduced with MAX)."""
+        nonlocal carrier
+        ax.single_process = args.single_process
+        if args.single_process:
+            import threading
+            from pyaudiodsptools_amd.engine import broadcast_filter, rccl_version
+            runners = []
+            for i in range(ndev):
                 torch.cuda.set_device(i)
-                results[i] = runners[i].measure(args.steps, args.warmup, gate.wait, args.prewarm_ms)
-            except BaseException as exc:  # a dead thread must not leave the others at the barrier
-                errors.append(exc)
-                gate.abort()
-        threads = [threading.Thread(target=work, args=(i,)) for i in range(ndev)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        if errors:
-            raise errors[0]
-        torch.cuda.set_device(0)
-        main_run = runners[0]
-        steps, warm, launches = results[0][0], results[0][1], results[0][4]
-        wall, kern_ms = max(r[2] for r in results), max(r[3] for r in results)
+                runners.append(Runner(ax, mode, fir_x, torch.device("cuda", i), i, 1, i))
+            broadcast_filter([r.eng for r in runners], 0)
+            carrier = f"adsp_bcast_spectrum (RCCL {rccl_version()} inside libadsp, ncclCommInitAll over {ndev} device(s), one process)"
+            gate = threading.Barrier(ndev)
+            errors, parity = [], [None] * ndev
+
+            def work(i):
+                try:
+                    torch.cuda.set_device(i)
+                    runners[i].measure(steps, warm, gate.wait, prewarm_ms, repeats=repeats, clock=clock and i == 0)
+                    if not args.no_parity_check:
+                        parity[i] = runners[i].parity_check(fir_x)
+                except BaseException as exc:  # a dead thread must not leave the others at the barrier
+                    errors.append(exc)
+                    gate.abort()
+            threads = [threading.Thread(target=work, args=(i,)) for i in range(ndev)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            if errors:
+                raise errors[0]
+            torch.cuda.set_device(0)
+            per = [r.last_runs for r in runners]
+            runs = [(max(p[k][0] for p in per), max(p[k][1] for p in per), per[0][k][2], per[0][k][3]) for k in range(len(per[0]))]
+            par = [p for p in parity if p]
+            pblock = max(par, key=lambda q: q["max_rel_err"]) if par else None
+            runners[0].peers = runners[1:]
+            return runners[0], runs, pblock
+        r = Runner(ax, mode, fir_x, dev, local_rank, world, rank)
+        r.measure(steps, warm, barrier, prewarm_ms, repeats=repeats, clock=clock)
+        runs = r.last_runs
+        pblock = None if args.no_parity_check else r.parity_check(fir_x)
+        if barrier is not None:
+            t = torch.tensor([x for run in runs for x in run[:2]] + [pblock["max_rel_err"] if pblock else 0.0], device=red_dev, dtype=torch.float64)
+            tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+            runs = [(float(t[2 * k]), float(t[2 * k + 1]), runs[k][2], runs[k][3]) for k in range(len(runs))]
+            if pblock:
+                pblock["max_rel_err"] = float(t[-1])
+                pblock["reduced"] = "max over ranks"
+        return r, runs, pblock
+
+    main_run, runs, parity = measure_everywhere(args, args.mode, fir, args.steps, args.warmup, args.prewarm_ms, args.runs, True)
+    steps, warm = max(1, args.steps), args.warmup
+    if args.single_process:
         world = ndev  # whole-job aggregate below
-    else:
-        main_run = Runner(args, args.mode, fir, dev, local_rank, world, rank)
-        steps, warm, wall, kern_ms, launches = main_run.measure(args.steps, args.warmup, barrier, args.prewarm_ms)
     dist_info = {}
-    if barrier is not None:
-        t = torch.tensor([wall, kern_ms], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
-        wall, kern_ms = float(t[0]), float(t[1])
-        # what the collective layer saw: the world size as torch.distributed reports it, and a 64-bit checksum of the
-        # spectrum every rank ended up with (all_gather): the broadcast is the path's only exchange step
+    if barrier is not None or args.single_process:
+        # what the collective layer saw: the world size, and a 64-bit checksum of the spectrum every rank's ENGINE ended up with
+        # (adsp_get_spectrum: the copy its tables were built from) - the broadcast is the path's only exchange step
         import hashlib
-        mine = int.from_bytes(hashlib.blake2b(np.ascontiguousarray(main_run.bank.spectrum).tobytes(), digest_size=8).digest(), "little", signed=True)
-        tl = torch.tensor([mine], device=dev if backend == "nccl" else "cpu", dtype=torch.int64)
-        gathered = [torch.zeros_like(tl) for _ in range(tdist.get_world_size())]
-        tdist.all_gather(gathered, tl)
-        sums = [int(g[0]) for g in gathered]
-        dist_info = {"ranks_seen": tdist.get_world_size(), "backend": tdist.get_backend(),
-                     "spectrum_checksum": {"blake2b64_rank0": f"{sums[0] & 0xFFFFFFFFFFFFFFFF:016x}", "equal_on_all_ranks": len(set(sums)) == 1}}
-        carrier = f"torch.distributed broadcast ({tdist.get_backend()}) -> " + ("adsp_set_spectrum_device" if backend == "nccl" else "adsp_set_spectrum")
+
+        def checksum(eng):
+            return int.from_bytes(hashlib.blake2b(np.ascontiguousarray(eng.get_spectrum()).tobytes(), digest_size=8).digest(), "little", signed=True)
+        if args.single_process:
+            sums = [checksum(r.eng) for r in [main_run] + getattr(main_run, "peers", [])]
+            dist_info = {"ranks_seen": ndev, "backend": "rccl inside libadsp (one process)"}
+        else:
+            tl = torch.tensor([checksum(main_run.eng)], device=red_dev, dtype=torch.int64)
+            gathered = [torch.zeros_like(tl) for _ in range(tdist.get_world_size())]
+            tdist.all_gather(gathered, tl)
+            sums = [int(g[0]) for g in gathered]
+            dist_info = {"ranks_seen": tdist.get_world_size(), "backend": tdist.get_backend()}
+            carrier = f"torch.distributed broadcast ({tdist.get_backend()}) -> " + ("adsp_set_spectrum_device" if backend == "nccl" else "adsp_set_spectrum")
+        dist_info["spectrum_checksum"] = {"blake2b64_rank0": f"{sums[0] & 0xFFFFFFFFFFFFFFFF:016x}", "equal_on_all_ranks": len(set(sums)) == 1,
+                                          "of": "adsp_get_spectrum of every rank's engine"}
+        if os.environ.get("ADSP_BENCH_REEXEC") == "1":
+            dist_info["launcher"] = "bench.py re-executed itself under torch.distributed.run (plain `python3 bench.py --gpus N`)"
+    med, runs_block = summarize_runs(runs, main_run.samples_per_step * world, steps)
+    wall, kern_ms, launches, _ = runs[med]
+    if parity is not None:
+        tol = 1e-5
+        parity["tolerance"] = tol if args.io == "f32" else "1 LSB (int16 export truncates)"
+        ok = (parity["max_rel_err"] <= tol) if args.io == "f32" else (parity["max_abs_err"] <= 1.0)
+        if not (ok and parity["scale"] > 0.05):
+            raise SystemExit(f"bench.py: PARITY FAILURE in the timed output: max|d| / max|truth| = {parity['max_rel_err']:.3e} > {tol} "
+                             f"({parity['channels']} channels x {parity['samples'] // max(1, parity['channels'])} samples against the float64 direct sum) - no line")
     sps, cps = main_run.samples_per_step, main_run.cps
     eng_desc = {"fft_size": main_run.eng.geometry.fft_size, "real": main_run.eng.real_spectrum,
                 "kept": N if args.mode == "stream" else main_run.eng.block_outputs, "taps": len(fir.taps)}
@@ -566,10 +714,11 @@ def main():
     # a scaling run is the BENCH line): configs[3] HighCut(8000) on 8192 channels x 4096 per GPU, configs[4] the fused
     # LowCut -> EQ3 -> HighCut chain @ 96 kHz on 4096 channels x 8192 per GPU.  Same step definition, same timing rules.
     extra_configs = None
-    if barrier is not None and world > 1 and args.mode == "batch" and args.io == "f32" and args.effect == "none":
+    if (barrier is not None or args.single_process) and world > 1 and args.mode == "batch" and args.io == "f32" and args.effect == "none":
         extra_configs = {}
         try:
-            del main_run.ins, main_run.outs
+            for r in [main_run] + getattr(main_run, "peers", []):
+                del r.ins, r.outs
             torch.cuda.empty_cache()
         except AttributeError:
             pass
@@ -577,18 +726,23 @@ def main():
                           ("config5_chain_4096ch_x_8192_96k", ["--filter", "chain", "--channels", "4096", "--chunk", "8192", "--fs", "96000"])):
             try:
                 ax = parse(argv)
-                rx = Runner(ax, "batch", make_fir(ax), dev, local_rank, world, rank)
-                x_steps, _, x_wall, x_kern, x_launches = rx.measure(max(2, min(args.steps, 8)), 2, barrier, min(args.prewarm_ms, 150.0))
-                t = torch.tensor([x_wall, x_kern], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-                tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
-                x_wall, x_kern = float(t[0]), float(t[1])
+                x_steps = max(2, min(args.steps, 8))
+                rx, x_runs, x_par = measure_everywhere(ax, "batch", make_fir(ax), x_steps, 2, min(args.prewarm_ms, 150.0), 3, False)
+                x_med, x_block = summarize_runs(x_runs, rx.samples_per_step * world, x_steps)
+                x_wall, x_kern, x_launches, _ = x_runs[x_med]
                 per = x_kern / 1e3 / x_launches
                 extra_configs[key] = {"value": round(rx.samples_per_step * world * x_steps / x_wall / 1e6, 1), "unit": "Msamples/s", "n_gpus": world,
                                       "steps": x_steps, "ms_per_step": round(x_wall * 1e3 / x_steps, 4),
                                       "workload": f"{FILTER_NAMES[ax.filter]} @ {ax.fs} Hz, {ax.channels} channels x {ax.chunk}-sample chunks per GPU, "
                                                   f"{rx.cps} chunks per step, {rx.eng.block_outputs} of {rx.eng.geometry.fft_size} samples kept per transform",
                                       "roofline_frac": round(ALG_BYTES_PER_SAMPLE * rx.samples_per_step / per / 1e9 / HBM_PEAK_GBS, 4),
-                                      "avg_launch_us": round(per * 1e6, 2)}
+                                      "avg_launch_us": round(per * 1e6, 2),
+                                      "runs_msamples_s": x_block["value_msamples_s"],
+                                      "parity_max_rel_err": None if not x_par else float(f"{x_par['max_rel_err']:.3e}")}
+                if x_par and not x_par["max_rel_err"] <= 1e-5:
+                    extra_configs[key]["error"] = "PARITY FAILURE against the float64 direct sum"
+                for r in [rx] + getattr(rx, "peers", []):
+                    del r.ins, r.outs
                 del rx
                 torch.cuda.empty_cache()
             except Exception as exc:
@@ -642,6 +796,11 @@ def main():
                          "launches": launches, "algorithmic_bytes_per_launch": int(alg_bytes * samples_per_launch),
                          "traffic_source": traffic_src},
         }
+        line["runs"] = runs_block
+        line["parity_checked"] = parity is not None
+        if parity is not None:
+            line["max_rel_err"] = float(f"{parity['max_rel_err']:.3e}")
+            line["parity"] = {k: (float(f"{v:.4e}") if isinstance(v, float) else v) for k, v in parity.items()}
         line.update(dist_info)
         if carrier:
             line["spectrum_carrier"] = carrier

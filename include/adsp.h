@@ -41,7 +41,7 @@ extern "C" {
 #define ADSP_API
 #endif
 
-#define ADSP_ABI_VERSION 7
+#define ADSP_ABI_VERSION 8
 #define ADSP_MAX_HISTORY 8
 
 typedef enum adsp_status {
@@ -153,6 +153,21 @@ ADSP_API int adsp_set_spectrum_device(adsp_engine* engine, const float* d_spectr
  * Channels never interact (each reference device is private state, Example2.py:13-21), so this is the only collective;
  * a one-process-per-GPU host (torchrun) uses its own RCCL and adsp_set_spectrum_device instead. */
 ADSP_API int adsp_bcast_spectrum(adsp_engine* const* engines, int n, int root);
+/* The same collective for a ONE-PROCESS-PER-GPU host (round 4): this process holds rank `rank` of `world` and one engine.
+ * Rank 0 draws 128 bytes with adsp_rccl_unique_id (ncclGetUniqueId) and hands them to every other rank by whatever means
+ * the host has - a file, an environment variable, MPI, a socket; pyaudiodsptools_amd.dist uses a file next to the
+ * rendezvous port - then EVERY rank calls adsp_bcast_spectrum_rank with the same id: the first call joins the communicator
+ * (ncclCommInitRank: RCCL's own bootstrap, no torch.distributed; cached per id for later filter changes), a header
+ * broadcast carries the root's geometry, sample format, spectrum precision and kernel-reach hint (a rank whose engine was
+ * built for another window layout fails with ADSP_ERR_ARG instead of filtering with the wrong offsets), the spectrum
+ * follows, and each rank rebuilds its tables from what the collective left in its own memory.  A float64 spectrum
+ * (adsp_set_spectrum_f64) travels as float64 in both forms of the collective.  Set-up path: the device is drained. */
+#define ADSP_RCCL_UNIQUE_ID_BYTES 128
+ADSP_API int adsp_rccl_unique_id(char* unique_id /* [ADSP_RCCL_UNIQUE_ID_BYTES] */);
+ADSP_API int adsp_bcast_spectrum_rank(adsp_engine* engine, const char* unique_id, int rank, int world, int root);
+/* The spectrum this engine's tables were last built from, n_bins = F/2+1 interleaved (re, im) float32 values - after a
+ * broadcast: what the collective left in this engine's device memory (bench.py checksums it across ranks). */
+ADSP_API int adsp_get_spectrum(const adsp_engine* engine, float* spectrum_interleaved, int n_bins);
 /* Version code of the RCCL that adsp_bcast_spectrum uses (ncclGetVersion); ADSP_ERR_STATE when none can be opened. */
 ADSP_API int adsp_rccl_version(int* version);
 
@@ -231,9 +246,11 @@ ADSP_API int adsp_apply_device(adsp_engine* engine, const void* d_in, void* d_ou
  *     k - ring_slots + history have read: adsp_ring_acquire_stream makes the producer's stream wait for those kernels.
  * Nothing is recorded while every step arrives on one stream; the first step on a different stream joins the old stream
  * once, and from then on each step costs two event records and up to history_chunks + 1 stream waits.  Producers must be
- * enqueued on the stream given to adsp_ring_acquire_stream; plain adsp_ring_acquire knows no stream and, once several
- * streams are in use, blocks the HOST until the slot's last readers have finished.  More slots than history_chunks + 1
- * let a producer run further ahead of the kernels; correctness does not depend on the count. */
+ * enqueued on the stream given to adsp_ring_acquire_stream.  adsp_ring_acquire_stream is MANDATORY for every step that is
+ * not issued on the previous step's stream - the first one on a new stream included: plain adsp_ring_acquire knows no
+ * stream, orders nothing while the library has seen a single stream (the stream itself orders that case), and only once
+ * several streams have been seen blocks the HOST until the slot's last readers have finished.  More slots than
+ * history_chunks + 1 let a producer run further ahead of the kernels; correctness does not depend on the count. */
 ADSP_API int adsp_ring_acquire(adsp_engine* engine, void** d_slot);
 ADSP_API int adsp_ring_acquire_stream(adsp_engine* engine, void** d_slot, void* stream);
 ADSP_API int adsp_apply_ring(adsp_engine* engine, void* d_out, void* stream);
@@ -295,6 +312,13 @@ ADSP_API int adsp_set_state(adsp_engine* engine, const void* host_history);
  * milliseconds and the number of launches since the last call, and clears the record. */
 ADSP_API int adsp_enable_kernel_timing(adsp_engine* engine, int enable);
 ADSP_API int adsp_kernel_time(adsp_engine* engine, double* total_ms, int* launches);
+
+/* Shader clock under load (bench.py, SURVEY 8d: the chip clocks to its power budget, so a throughput figure is only
+ * comparable together with the clock it ran at): adsp_clock_probe_launch enqueues a one-lane kernel on `stream` - a side
+ * stream next to the timed launches - that counts shader cycles (s_memtime) over `microseconds` of the constant 100 MHz
+ * clock; adsp_clock_probe_read waits for `stream`, returns cycles / time in MHz and frees `result`. */
+ADSP_API int adsp_clock_probe_launch(int device_id, double microseconds, void* stream, unsigned long long** result);
+ADSP_API int adsp_clock_probe_read(int device_id, void* stream, unsigned long long* result, double* shader_mhz);
 
 /* Block until everything this engine enqueued on `stream` is done. */
 ADSP_API int adsp_synchronize(adsp_engine* engine, void* stream);

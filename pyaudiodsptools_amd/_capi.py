@@ -6,8 +6,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADSP_LIB") or os.path.join(_HERE, "libadsp.so")  # ADSP_LIB: tuning builds only
 
-ADSP_ABI_VERSION = 7
+ADSP_ABI_VERSION = 8
 ADSP_MAX_HISTORY = 8
+ADSP_RCCL_UNIQUE_ID_BYTES = 128
 ADSP_FORMAT_F32, ADSP_FORMAT_S16, ADSP_FORMAT_S16_F64 = 0, 1, 2
 EFFECT_NONE, EFFECT_VOLUME, EFFECT_SOFT_CLIPPER, EFFECT_HARD_DISTORTION, EFFECT_SATURATOR, EFFECT_TREMOLO = 0, 1, 2, 3, 4, 5
 EFFECT_BIT_CRUSHER = 6
@@ -116,6 +117,11 @@ SIGNATURES = {
     "adsp_ring_resident_status": (ctypes.c_int, [_engine_p, _c_int_p]),
     "adsp_bcast_spectrum": (ctypes.c_int, [ctypes.POINTER(_engine_p), ctypes.c_int, ctypes.c_int]),
     "adsp_rccl_version": (ctypes.c_int, [_c_int_p]),
+    "adsp_rccl_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
+    "adsp_bcast_spectrum_rank": (ctypes.c_int, [_engine_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "adsp_get_spectrum": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_int]),
+    "adsp_clock_probe_launch": (ctypes.c_int, [ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "adsp_clock_probe_read": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]),
     "adsp_apply_ring": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_void_p]),
     "adsp_get_state": (ctypes.c_int, [_engine_p, ctypes.c_void_p]),
     "adsp_set_state": (ctypes.c_int, [_engine_p, ctypes.c_void_p]),

@@ -20,6 +20,8 @@
 namespace adsp {  // adsp_rccl.hip
 int rccl_broadcast(float* const* d_buf, const int* devs, const hipStream_t* streams, int n, size_t count, int root);
 int rccl_version(int* version);
+int rccl_unique_id(char* out);
+int rccl_broadcast_rank(const char* unique_id, int rank, int world, int root, int dev, float* d_buf, size_t count, hipStream_t stream);
 }  // namespace adsp
 
 // standalone elementwise form of the fused output effects (fftconv_kernel.hpp::epilogue_value): out[i] = effect(in[i]);
@@ -92,6 +94,20 @@ __global__ void adsp_mix_kernel(MixArgs a, float* __restrict__ out, size_t n) {
             if (j < a.k) acc += a.in[j][i];
         out[i] = a.clip ? __builtin_amdgcn_fmed3f(acc, -1.f, 1.f) : acc;
     }
+}
+
+// Shader clock while a workload runs (bench.py): one lane counts shader cycles (s_memtime) over a stretch of the constant
+// 100 MHz clock (s_memrealtime), sleeping between reads - launched on a side stream next to the timed kernels.
+__global__ void adsp_clock_probe_kernel(unsigned long long* out, unsigned long long ticks) {
+    const unsigned long long w0 = wall_clock64();
+    const unsigned long long c0 = clock64();
+    unsigned long long w1 = w0;
+    while (w1 - w0 < ticks) {
+        __builtin_amdgcn_s_sleep(64);
+        w1 = wall_clock64();
+    }
+    out[0] = clock64() - c0;
+    out[1] = w1 - w0;
 }
 
 namespace {
@@ -275,6 +291,7 @@ struct adsp_engine {
     bool have_spectrum;
     bool real_spec;  // every Im H == 0: the kernel takes the 3-real-constants-per-pair path
     std::vector<float> host_spec;  // the spectrum last set, interleaved (adsp_bcast_spectrum sends the root's)
+    std::vector<double> host_spec64;  // ... when it was given in float64 (adsp_set_spectrum_f64): broadcast as it is
     float* d_spec;                 // 2 (M + 1) floats on the device: the buffer the RCCL broadcast runs on (lazily allocated)
     // stream-ordered table updates (adsp_set_spectrum_async): two pinned staging buffers, reused alternately
     char* pin_tab[2];
@@ -321,8 +338,10 @@ struct adsp_engine {
         hipStream_t waited_by = nullptr;  // the producer stream that already waits for `done` (one wait per launch, not per slot)
         bool waited = false;
     };
-    std::vector<ResidentLaunch> resident_launches;  // the most recent ones (ring order of producers against their readers)
-    size_t resident_next;
+    std::vector<ResidentLaunch> resident_launches;  // every launch that may still be running (entries are reused once their
+                                                    // `done` event has fired: the table grows with the launches in flight)
+    hipEvent_t ev_pub;        // recorded on the producer stream behind the most recent publication
+    bool have_pub;
     bool resident_mode;
     unsigned* d_seq;          // [0] sequence word = number of steps published so far, [1] time-out flag; fine-grained device memory
     unsigned pub_count;       // host copy of the sequence word once every enqueued publication has executed
@@ -375,8 +394,10 @@ int upload_pairs_t(adsp_engine* e, const HT* H, hipStream_t stream, bool async) 
     e->real_spec = real_spec;
     if constexpr (std::is_same<HT, float>::value) {
         if (e->host_spec.data() != H) e->host_spec.assign(H, H + 2 * (size_t)(M + 1));
+        e->host_spec64.clear();
     } else {
-        e->host_spec.clear();  // (a float64 spectrum is not kept: adsp_bcast_spectrum carries float32 spectra)
+        e->host_spec.clear();
+        if (e->host_spec64.data() != H) e->host_spec64.assign(H, H + 2 * (size_t)(M + 1));
     }
     // float4 layout [u][h][3][T]: (wc,g1) of pair 2h, (g2 of 2h, wc of 2h+1), (g1,g2) of 2h+1
     std::vector<T4> tab((size_t)PU * (npairs / 2) * 3 * T, V::m4(0, 0, 0, 0));
@@ -478,6 +499,13 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
     // every step already published: nothing will wait, so the launch may run in the multi-step order (a channel group's steps
     // are neighbours in the grid: their window overlap is an L2 hit); otherwise strictly step-major
     a.step_tile = (resident && e->lead >= n_steps) ? n_steps : 1;
+    if (resident && a.step_tile > 1 && e->have_pub) {
+        // `lead` counts publications ENQUEUED on the producer stream.  The tiled order lets later-step workgroups occupy CU
+        // slots ahead of earlier ones, so nothing of this launch may start before those publications have executed: an
+        // event wait on the consumer stream (free when they already have) instead of in-kernel waiting
+        if (hipEventQuery(e->ev_pub) != hipSuccess) HIP_TRY(hipStreamWaitEvent(stream, e->ev_pub, 0));
+        (void)hipGetLastError();  // (hipErrorNotReady from the query is not an error)
+    }
     a.seq = resident ? e->d_seq : nullptr;
     a.seq_base = e->pub_count - (unsigned)e->lead;  // (wraps like the word itself)
     a.seq_fail = resident ? e->d_seq + 1 : nullptr;
@@ -661,7 +689,8 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     e->ev_pin[0] = e->ev_pin[1] = e->ev_kernel = nullptr;
     e->want_kernel_event = false;
     e->timing = false;
-    e->resident_next = 0;
+    e->ev_pub = nullptr;
+    e->have_pub = false;
     e->resident_mode = false;
     e->d_seq = nullptr;
     e->pub_count = 0;
@@ -732,6 +761,7 @@ int adsp_destroy(adsp_engine* e) {
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     for (auto& rl : e->resident_launches)
         if (rl.done) (void)hipEventDestroy(rl.done);
+    if (e->ev_pub) (void)hipEventDestroy(e->ev_pub);
     if (e->d_seq) (void)hipFree(e->d_seq);
     if (e->pin_seq) (void)hipHostFree(e->pin_seq);
     for (auto& st : e->ring_steps) {
@@ -790,6 +820,41 @@ int adsp_set_spectrum_device(adsp_engine* e, const float* d_spectrum, int n_bins
     return upload_pairs(e, host.data(), (hipStream_t)stream, true);
 }
 
+namespace {
+// What travels: the root's spectrum as it was given - 2 (M + 1) floats, or 2 (M + 1) doubles moved as twice as many floats
+// (a broadcast moves bytes) for a float64 spectrum (adsp_set_spectrum_f64: the exact-FFT engines keep their precision).
+size_t bcast_floats(const adsp_engine* e, bool is64) { return 2 * (size_t)(e->M + 1) * (is64 ? 2 : 1); }
+
+int bcast_stage_root(adsp_engine* e, bool is64) {  // root: spectrum -> its device buffer, on its side stream
+    const size_t bytes = bcast_floats(e, is64) * sizeof(float);
+    HIP_TRY(hipMemcpyAsync(e->d_spec, is64 ? (const void*)e->host_spec64.data() : (const void*)e->host_spec.data(), bytes,
+                           hipMemcpyHostToDevice, e->copy_stream));
+    return ADSP_OK;
+}
+
+int bcast_buffer(adsp_engine* e) {  // large enough for either precision
+    if (!e->d_spec) HIP_TRY(hipMalloc(&e->d_spec, bcast_floats(e, true) * sizeof(float)));
+    return ADSP_OK;
+}
+
+// every engine, the root included, rebuilds its tables from what the collective left in ITS memory
+int bcast_adopt(adsp_engine* e, bool is64, int reach) {
+    int rc = set_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());  // set-up path: the tables may still be in use by queued launches
+    if (is64) {
+        std::vector<double> host(2 * (size_t)(e->M + 1));
+        HIP_TRY(hipMemcpy(host.data(), e->d_spec, host.size() * sizeof(double), hipMemcpyDeviceToHost));
+        if ((rc = upload_pairs(e, nullptr, nullptr, false, host.data()))) return rc;
+    } else {
+        if ((rc = adsp_set_spectrum_device(e, e->d_spec, e->M + 1, e->copy_stream))) return rc;
+        HIP_TRY(hipStreamSynchronize(e->copy_stream));
+    }
+    e->kernel_reach = reach;  // same kernel, same reach
+    return ADSP_OK;
+}
+}  // namespace
+
 // The one collective of the multi-GPU path: every engine takes over the ROOT engine's filter.  One process, n devices.
 int adsp_bcast_spectrum(adsp_engine* const* engines, int n, int root) {
     if (!engines || n < 1) return fail(ADSP_ERR_ARG, "need at least one engine");
@@ -803,7 +868,8 @@ int adsp_bcast_spectrum(adsp_engine* const* engines, int n, int root) {
     }
     const adsp_engine* r = engines[root];
     if (!r->have_spectrum) return fail(ADSP_ERR_STATE, "the root engine has no spectrum yet (adsp_set_spectrum)");
-    if (r->host_spec.empty()) return fail(ADSP_ERR_STATE, "the root engine's spectrum was given in float64 (adsp_set_spectrum_f64): broadcasts carry float32 spectra");
+    const bool is64 = r->host_spec.empty();
+    if (is64 && r->host_spec64.empty()) return fail(ADSP_ERR_STATE, "internal: the root engine kept no copy of its spectrum");
     for (int i = 0; i < n; ++i) {
         // a spectrum only means something together with the window geometry it was designed for
         const adsp_config &a = engines[i]->cfg, &b = r->cfg;
@@ -812,7 +878,7 @@ int adsp_bcast_spectrum(adsp_engine* const* engines, int n, int root) {
             return fail(ADSP_ERR_ARG, "engine %d has a different geometry than the root engine (chunk %d/%d, fft %d/%d, lookback %d/%d, "
                         "out_offset %d/%d)", i, a.chunk_size, b.chunk_size, a.fft_size, b.fft_size, a.lookback, b.lookback, a.out_offset, b.out_offset);
     }
-    const size_t count = 2 * (size_t)(r->M + 1);
+    const size_t count = bcast_floats(r, is64);
     std::vector<float*> bufs(n);
     std::vector<int> devs(n);
     std::vector<hipStream_t> streams(n);
@@ -820,29 +886,73 @@ int adsp_bcast_spectrum(adsp_engine* const* engines, int n, int root) {
         adsp_engine* e = engines[i];
         int rc = set_device(e);
         if (rc) return rc;
-        if (!e->d_spec) HIP_TRY(hipMalloc(&e->d_spec, count * sizeof(float)));
+        if ((rc = bcast_buffer(e))) return rc;
         bufs[i] = e->d_spec;
         devs[i] = e->cfg.device_id;
         streams[i] = e->copy_stream;  // the engine's own side stream: nothing of the caller's is ordered behind the collective
     }
-    {
-        adsp_engine* e = engines[root];
-        int rc = set_device(e);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(e->d_spec, e->host_spec.data(), count * sizeof(float), hipMemcpyHostToDevice, e->copy_stream));
-    }
-    int rc = adsp::rccl_broadcast(bufs.data(), devs.data(), streams.data(), n, count, root);
+    int rc = set_device(engines[root]);
     if (rc) return rc;
+    if ((rc = bcast_stage_root(engines[root], is64))) return rc;
+    if ((rc = adsp::rccl_broadcast(bufs.data(), devs.data(), streams.data(), n, count, root))) return rc;
     const int reach = r->kernel_reach;
-    for (int i = 0; i < n; ++i) {
-        // every engine, the root included, rebuilds its tables from what the collective left in ITS memory
-        adsp_engine* e = engines[i];
-        if ((rc = set_device(e))) return rc;
-        HIP_TRY(hipDeviceSynchronize());  // set-up path: the tables may still be in use by queued launches
-        if ((rc = adsp_set_spectrum_device(e, e->d_spec, r->M + 1, e->copy_stream))) return rc;
-        HIP_TRY(hipStreamSynchronize(e->copy_stream));
-        e->kernel_reach = reach;  // same kernel, same reach
+    for (int i = 0; i < n; ++i)
+        if ((rc = bcast_adopt(engines[i], is64, reach))) return rc;
+    return ADSP_OK;
+}
+
+int adsp_rccl_unique_id(char* unique_id) {
+    if (!unique_id) return fail(ADSP_ERR_ARG, "unique_id is NULL");
+    return adsp::rccl_unique_id(unique_id);
+}
+
+// The same collective for a ONE-PROCESS-PER-GPU job: this process holds rank `rank` of `world`.
+int adsp_bcast_spectrum_rank(adsp_engine* e, const char* unique_id, int rank, int world, int root) {
+    if (!e || !unique_id) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (world < 1 || rank < 0 || rank >= world || root < 0 || root >= world)
+        return fail(ADSP_ERR_ARG, "rank %d / root %d out of range for a world of %d", rank, root, world);
+    int rc = set_device(e);
+    if (rc) return rc;
+    if ((rc = bcast_buffer(e))) return rc;
+    // header first: the root says what it sends, every rank checks it against its own engine (a rank that derived another
+    // window layout must fail loudly instead of filtering with the wrong offsets)
+    float* d_hdr = e->d_spec;  // the spectrum buffer doubles as the 8-float header buffer
+    float hdr[8] = {0};
+    bool is64 = false;
+    if (rank == root) {
+        if (!e->have_spectrum) return fail(ADSP_ERR_STATE, "the root engine has no spectrum yet (adsp_set_spectrum)");
+        is64 = e->host_spec.empty();
+        if (is64 && e->host_spec64.empty()) return fail(ADSP_ERR_STATE, "internal: the root engine kept no copy of its spectrum");
+        const float h[8] = {(float)e->cfg.chunk_size, (float)e->cfg.fft_size, (float)e->cfg.history_chunks, (float)e->cfg.lookback,
+                            (float)e->cfg.out_offset, (float)e->cfg.sample_format, is64 ? 1.f : 0.f, (float)e->kernel_reach};
+        memcpy(hdr, h, sizeof hdr);
+        HIP_TRY(hipMemcpyAsync(d_hdr, hdr, sizeof hdr, hipMemcpyHostToDevice, e->copy_stream));
+        HIP_TRY(hipStreamSynchronize(e->copy_stream));  // (hdr is a stack array)
     }
+    if ((rc = adsp::rccl_broadcast_rank(unique_id, rank, world, root, e->cfg.device_id, d_hdr, 8, e->copy_stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(hdr, d_hdr, sizeof hdr, hipMemcpyDeviceToHost, e->copy_stream));
+    HIP_TRY(hipStreamSynchronize(e->copy_stream));
+    const adsp_config& c = e->cfg;
+    const int mine[6] = {c.chunk_size, c.fft_size, c.history_chunks, c.lookback, c.out_offset, c.sample_format};
+    for (int i = 0; i < 6; ++i)
+        if ((int)hdr[i] != mine[i])
+            return fail(ADSP_ERR_ARG, "rank %d: engine geometry (chunk %d, fft %d, history %d, lookback %d, out_offset %d, format %d) differs from "
+                        "rank %d's (%d, %d, %d, %d, %d, %d)", rank, mine[0], mine[1], mine[2], mine[3], mine[4], mine[5], root, (int)hdr[0],
+                        (int)hdr[1], (int)hdr[2], (int)hdr[3], (int)hdr[4], (int)hdr[5]);
+    is64 = hdr[6] != 0.f;
+    const int reach = (int)hdr[7];
+    if (rank == root && (rc = bcast_stage_root(e, is64))) return rc;
+    if ((rc = adsp::rccl_broadcast_rank(unique_id, rank, world, root, e->cfg.device_id, e->d_spec, bcast_floats(e, is64), e->copy_stream))) return rc;
+    return bcast_adopt(e, is64, reach);
+}
+
+int adsp_get_spectrum(const adsp_engine* e, float* spectrum, int n_bins) {
+    if (!e || !spectrum) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (n_bins != e->M + 1) return fail(ADSP_ERR_ARG, "n_bins %d != fft_size/2+1 = %d", n_bins, e->M + 1);
+    if (!e->have_spectrum) return fail(ADSP_ERR_STATE, "adsp_set_spectrum has not been called");
+    const size_t n = 2 * (size_t)n_bins;
+    if (!e->host_spec.empty()) memcpy(spectrum, e->host_spec.data(), n * sizeof(float));
+    else for (size_t i = 0; i < n; ++i) spectrum[i] = (float)e->host_spec64[i];
     return ADSP_OK;
 }
 
@@ -1090,7 +1200,7 @@ int resident_prepare(adsp_engine* e) {
         HIP_TRY(hipMemset(e->d_seq, 0, 2 * sizeof(unsigned)));
         HIP_TRY(hipDeviceSynchronize());
         e->pub_count = 0;
-        e->resident_launches.resize(8);
+        e->resident_launches.reserve(8);
     }
     e->resident_mode = true;
     return ADSP_OK;
@@ -1352,6 +1462,12 @@ int adsp_ring_produce_end(adsp_engine* e, void* stream_v) {
         *src = value;
         HIP_TRY(hipMemcpyAsync(e->d_seq, src, sizeof(unsigned), hipMemcpyHostToDevice, stream));
     }
+    // consumer launches that find every one of their steps published run in the tiled workgroup order, in which a workgroup
+    // of a later step may be dispatched before one of an earlier step: they must not start before the publications have
+    // EXECUTED (not merely been enqueued) - launch() makes the consumer stream wait for this event
+    if (!e->ev_pub) HIP_TRY(hipEventCreateWithFlags(&e->ev_pub, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(e->ev_pub, stream));
+    e->have_pub = true;
     e->pub_count = value;
     e->lead += e->pub_pending;
     e->pub_pending = 0;
@@ -1375,7 +1491,21 @@ int adsp_apply_ring_resident(adsp_engine* e, void* d_out, int n_steps, void* str
     }
     hipStream_t run = stream;
     if ((rc = launch(e, e->ring, d_out, n_steps, run, true))) return rc;
-    auto& rl = e->resident_launches[e->resident_next++ % e->resident_launches.size()];
+    // an entry is reusable once its launch has finished (no producer needs to wait for it any more); otherwise the table
+    // grows - a large ring consumed by many small launches has many of them in flight, and evicting one would let a
+    // producer overwrite a slot that a queued launch has yet to read
+    adsp_engine::ResidentLaunch* slot_rl = nullptr;
+    for (auto& cand : e->resident_launches)
+        if (cand.n == 0 || (cand.done && hipEventQuery(cand.done) == hipSuccess)) {
+            slot_rl = &cand;
+            break;
+        }
+    (void)hipGetLastError();
+    if (!slot_rl) {
+        e->resident_launches.emplace_back();
+        slot_rl = &e->resident_launches.back();
+    }
+    auto& rl = *slot_rl;
     if (!rl.done) HIP_TRY(hipEventCreateWithFlags(&rl.done, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(rl.done, run));
     rl.first = e->step_no;
@@ -1532,6 +1662,42 @@ int adsp_kernel_time(adsp_engine* e, double* total_ms, int* launches) {
     *launches = (int)e->timed.size();
     e->free_ev.insert(e->free_ev.end(), e->timed.begin(), e->timed.end());
     e->timed.clear();
+    return ADSP_OK;
+}
+
+int adsp_clock_probe_launch(int device_id, double microseconds, void* stream, unsigned long long** result) {
+    if (!result) return fail(ADSP_ERR_ARG, "result is NULL");
+    if (!(microseconds > 0.0) || microseconds > 1e6) return fail(ADSP_ERR_ARG, "probe length must be in (0, 1e6] us");
+    HIP_TRY(hipSetDevice(device_id));
+    unsigned long long* host = nullptr;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&host), 2 * sizeof(unsigned long long), hipHostMallocMapped));
+    host[0] = host[1] = 0;
+    void* dptr = nullptr;
+    hipError_t err = hipHostGetDevicePointer(&dptr, host, 0);
+    if (err != hipSuccess) {
+        (void)hipHostFree(host);
+        return fail(ADSP_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(err));
+    }
+    hipLaunchKernelGGL(adsp_clock_probe_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, static_cast<unsigned long long*>(dptr),
+                       (unsigned long long)(microseconds * 100.0));
+    err = hipGetLastError();
+    if (err != hipSuccess) {
+        (void)hipHostFree(host);
+        return fail(ADSP_ERR_HIP, "clock probe launch: %s", hipGetErrorString(err));
+    }
+    *result = host;
+    return ADSP_OK;
+}
+
+int adsp_clock_probe_read(int device_id, void* stream, unsigned long long* result, double* shader_mhz) {
+    if (!result || !shader_mhz) return fail(ADSP_ERR_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(device_id));
+    hipError_t err = hipStreamSynchronize((hipStream_t)stream);
+    const unsigned long long cycles = result[0], ticks = result[1];
+    (void)hipHostFree(result);
+    if (err != hipSuccess) return fail(ADSP_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(err));
+    if (!ticks) return fail(ADSP_ERR_STATE, "the clock probe has not run");
+    *shader_mhz = (double)cycles / (double)ticks * 100.0;
     return ADSP_OK;
 }
 

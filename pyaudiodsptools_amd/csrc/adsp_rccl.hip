@@ -3,13 +3,18 @@
 // libadsp.so does not link librccl: it is opened on first use (dlopen), so the single-GPU product has no RCCL dependency
 // and a process that already carries an RCCL (PyTorch-ROCm bundles one) shares it.  The communicator is built with
 // ncclCommInitAll - ONE process driving n devices needs no rendezvous - and cached per device list.
+// A one-process-per-GPU host (torchrun, MPI, anything that can hand 128 bytes from rank 0 to the others) uses
+// rccl_broadcast_rank instead: rank 0 draws an id (ncclGetUniqueId), every rank joins with ncclCommInitRank - RCCL's own
+// bootstrap over the loopback / host network, no torch.distributed - and the communicator is cached per (id, rank, world).
 // The reference has no counterpart: its devices are independent Python objects that each design their own filter
 // (Example2.py:13-14).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cstring>
 #include <map>
+#include <string>
 #include <mutex>
 #include <vector>
 
@@ -22,9 +27,14 @@ namespace {
 typedef void* comm_t;
 constexpr int kNcclSuccess = 0;
 constexpr int kNcclFloat32 = 7;
+struct UniqueId {  // rccl.h: typedef struct { char internal[NCCL_UNIQUE_ID_BYTES = 128]; } ncclUniqueId - passed BY VALUE
+    char internal[ADSP_RCCL_UNIQUE_ID_BYTES];
+};
 struct Api {
     void* handle = nullptr;
     int (*CommInitAll)(comm_t*, int, const int*) = nullptr;
+    int (*GetUniqueId)(UniqueId*) = nullptr;
+    int (*CommInitRank)(comm_t*, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(comm_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
@@ -36,6 +46,7 @@ struct Api {
 std::mutex g_mu;
 Api g_api;
 std::map<std::vector<int>, std::vector<comm_t>> g_comms;  // device list -> one communicator per device
+std::map<std::string, comm_t> g_rank_comms;               // (unique id, rank, world, device) -> this process's communicator
 
 int load_api() {
     if (g_api.handle) return ADSP_OK;
@@ -53,13 +64,15 @@ int load_api() {
     Api a;
     a.handle = h;
     a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
     a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
     a.Broadcast = reinterpret_cast<decltype(a.Broadcast)>(dlsym(h, "ncclBroadcast"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
     a.GetVersion = reinterpret_cast<decltype(a.GetVersion)>(dlsym(h, "ncclGetVersion"));
-    if (!a.CommInitAll || !a.CommDestroy || !a.GroupStart || !a.GroupEnd || !a.Broadcast || !a.GetErrorString)
+    if (!a.CommInitAll || !a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.GroupStart || !a.GroupEnd || !a.Broadcast || !a.GetErrorString)
         return adsp::fail(ADSP_ERR_STATE, "librccl.so lacks a symbol this library needs");
     g_api = a;
     return ADSP_OK;
@@ -98,6 +111,38 @@ int rccl_broadcast(float* const* d_buf, const int* devs, const hipStream_t* stre
         }
     }
     NCCL_TRY(g_api.GroupEnd());
+    return ADSP_OK;
+}
+
+// rank 0 of a one-process-per-GPU job: 128 bytes to hand to every other rank (file, environment, MPI, a socket ...)
+int rccl_unique_id(char* out) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    int rc = load_api();
+    if (rc) return rc;
+    UniqueId id;
+    memset(&id, 0, sizeof id);
+    NCCL_TRY(g_api.GetUniqueId(&id));
+    memcpy(out, id.internal, sizeof id.internal);
+    return ADSP_OK;
+}
+
+// d_buf: `count` floats on device `dev` of THIS process (rank `rank` of `world`); stream-ordered on `stream`, every rank's
+// buffer then holds root's.  The first call with a given id builds the communicator (collective: every rank must call).
+int rccl_broadcast_rank(const char* unique_id, int rank, int world, int root, int dev, float* d_buf, size_t count, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    int rc = load_api();
+    if (rc) return rc;
+    std::string key(unique_id, ADSP_RCCL_UNIQUE_ID_BYTES);
+    key += ":" + std::to_string(rank) + "/" + std::to_string(world) + "@" + std::to_string(dev);
+    auto it = g_rank_comms.find(key);
+    if (it == g_rank_comms.end()) {
+        UniqueId id;
+        memcpy(id.internal, unique_id, sizeof id.internal);
+        comm_t comm = nullptr;
+        NCCL_TRY(g_api.CommInitRank(&comm, world, id, rank));
+        it = g_rank_comms.emplace(key, comm).first;
+    }
+    NCCL_TRY(g_api.Broadcast(d_buf, d_buf, count, kNcclFloat32, root, it->second, stream));
     return ADSP_OK;
 }
 

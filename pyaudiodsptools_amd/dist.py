@@ -3,10 +3,16 @@
 Channels never interact (each reference device instance is private state, Example2.py:13-21), so
 the N-GPU job is N independent engines over contiguous channel ranges.  The only collective is ONE
 broadcast of the filter spectrum (complex64, 32 KiB at N = 4096) from rank 0 at filter
-creation/change - RCCL over xGMI on the GPU box (backend "nccl"), gloo in the CPU tests.  One
-process per GPU, launched by torchrun / torch.distributed.run.
+creation/change.  One process per GPU, launched by torchrun / torch.distributed.run.  Two carriers:
+
+  "torch"  torch.distributed (backend "nccl" IS RCCL on ROCm; gloo in the CPU tests), the spectrum then goes into the
+           engine with adsp_set_spectrum_device - the default when a process group exists;
+  "abi"    adsp_bcast_spectrum_rank: RCCL opened by libadsp itself (ncclCommInitRank), the 128-byte id handed from
+           rank 0 to the others through a small file - no torch.distributed anywhere (the default when WORLD_SIZE > 1
+           and no process group was initialised; force with ADSP_DIST_CARRIER=abi).
 """
 import os
+import time
 
 import numpy as np
 
@@ -40,6 +46,51 @@ def init_process_group(backend=None):
     return dist
 
 
+_job_unique_id = None
+
+
+def exchange_unique_id(rank, world, make_id, path=None, timeout=120.0):
+    """Hand the 128 bytes `make_id()` returns on rank 0 to every rank of a one-process-per-GPU job - once per process (the
+    communicator behind it is cached by libadsp and reused for every later broadcast).
+
+    The carrier is a file: `path`, or $ADSP_RCCL_ID_FILE, or <tmp>/adsp_rccl_<MASTER_PORT>_<parent pid> (ranks started by
+    one torchrun agent share the parent, so two jobs on one box never read each other's id; launchers without a common
+    parent set ADSP_RCCL_ID_FILE).  Rank 0 writes it atomically (temporary file + rename) and removes it at exit."""
+    global _job_unique_id
+    if _job_unique_id is not None:
+        return _job_unique_id
+    if world == 1:
+        _job_unique_id = make_id()
+        return _job_unique_id
+    import tempfile
+    path = path or os.environ.get("ADSP_RCCL_ID_FILE") or os.path.join(
+        tempfile.gettempdir(), f"adsp_rccl_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
+    if rank == 0:
+        uid = bytes(make_id())
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as fh:
+            fh.write(uid)
+        os.replace(tmp, path)
+        import atexit
+        atexit.register(lambda: os.path.exists(path) and os.remove(path))
+    else:
+        t0 = time.time()
+        while True:
+            try:
+                with open(path, "rb") as fh:
+                    uid = fh.read()
+                if len(uid) >= 128:
+                    uid = uid[:128]
+                    break
+            except FileNotFoundError:
+                pass
+            if time.time() - t0 > timeout:
+                raise TimeoutError(f"rank {rank}: no RCCL id from rank 0 in {path} after {timeout:.0f} s")
+            time.sleep(0.01)
+    _job_unique_id = uid
+    return uid
+
+
 def broadcast_spectrum(spectrum_f32, src=0, device=None):
     """Broadcast the interleaved float32 spectrum from `src`; returns (tensor, numpy copy).
 
@@ -64,19 +115,42 @@ class ShardedFirBank:
     it to its own engine (bit-identical spectra across ranks by construction)."""
 
     def __init__(self, fir, total_channels, device=0, ring_slots=0, engine_factory=None, fft_mult=0,
-                 sample_format="f32", optimize_for="stream"):
+                 sample_format="f32", optimize_for="stream", carrier=None):
         from .design import engine_spectrum, overlap_save_geometry
         rank, _, world = env_world()
+        pg = False
         try:
             import torch.distributed as dist
             if dist.is_initialized():
-                rank, world = dist.get_rank(), dist.get_world_size()
+                rank, world, pg = dist.get_rank(), dist.get_world_size(), True
         except ImportError:
             pass
         self.rank, self.world = rank, world
         self.lo, self.hi = shard_range(total_channels, world, rank)
         self.total_channels = int(total_channels)
         geo = overlap_save_geometry(fir, fft_mult, optimize_for)
+        carrier = carrier or os.environ.get("ADSP_DIST_CARRIER") or ("torch" if pg or world == 1 else "abi")
+        if carrier not in ("torch", "abi"):
+            raise ValueError("carrier must be 'torch' or 'abi'")
+        self.carrier = carrier
+        kw = dict(**({'fft_mult': fft_mult} if fft_mult else {}), **({'sample_format': sample_format} if sample_format != "f32" else {}),
+                  **({'optimize_for': optimize_for} if optimize_for != "stream" else {}))
+        if carrier == "abi":
+            # the collective lives behind the C ABI: every rank builds its engine (a rank without channels a one-channel stand-in,
+            # it still has to take part), rank 0's filter reaches the others through adsp_bcast_spectrum_rank
+            from .engine import FirEngine, rccl_unique_id
+            factory = engine_factory or FirEngine
+            eng = factory(fir, channels=max(1, self.hi - self.lo), device=device, ring_slots=ring_slots, **kw)
+            uid = exchange_unique_id(rank, world, rccl_unique_id)
+            eng.bcast_rank(uid, rank, world, 0)
+            self.spectrum = eng.spectrum
+            self.spectrum_tensor = None
+            if self.hi == self.lo:
+                if hasattr(eng, "close"):
+                    eng.close()
+                eng = None
+            self.engine = eng
+            return
         n_floats = 2 * (geo.fft_size // 2 + 1)
         from .design import PCM16_GAIN
         gain = PCM16_GAIN if sample_format == "s16" else 1.0
@@ -103,11 +177,15 @@ class ShardedFirBank:
         if self.hi == self.lo:  # more ranks than channels: this rank idles (it still took part in the broadcasts)
             self.engine = None
             return
-        self.engine = engine_factory(fir, channels=self.hi - self.lo, device=device, ring_slots=ring_slots,
-                                     **({'fft_mult': fft_mult} if fft_mult else {}),
-                                     **({'sample_format': sample_format} if sample_format != "f32" else {}),
-                                     **({'optimize_for': optimize_for} if optimize_for != "stream" else {}))
-        if bdev is not None and hasattr(self.engine, "upload_spectrum_device"):
+        self.engine = engine_factory(fir, channels=self.hi - self.lo, device=device, ring_slots=ring_slots, **kw)
+        if sample_format == "s16_f64":
+            # the exact-FFT engines keep float64 tables: the float32 broadcast above is the cross-rank agreement check only
+            # (every rank designs the same filter in float64; replacing the tables with the float32 copy would throw the
+            # engine's precision away while it still ran at a third of the rate)
+            mine32 = engine_spectrum(fir, geo, gain)
+            if not np.array_equal(mine32, self.spectrum):
+                raise ValueError(f"rank {rank}: this rank's filter differs from rank 0's - float64 engines need the same FirStream on every rank")
+        elif bdev is not None and hasattr(self.engine, "upload_spectrum_device"):
             # RCCL path: the spectrum the collective left in this GPU's memory goes straight into the engine
             # (adsp_set_spectrum_device); the collective ran on torch's current stream, which is drained first
             import torch

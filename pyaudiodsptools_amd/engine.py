@@ -113,6 +113,22 @@ class FirEngine:
         if reach is not None:
             _capi.check(self._lib.adsp_set_kernel_reach(self._h, int(reach)))
 
+    def get_spectrum(self):
+        """The interleaved float32 spectrum the engine's tables were last built from (after a broadcast: what the collective
+        left in this engine's device memory)."""
+        out = np.empty(2 * (self.geometry.fft_size // 2 + 1), np.float32)
+        _capi.check(self._lib.adsp_get_spectrum(self._h, _ptr(out), out.size // 2))
+        return out
+
+    def bcast_rank(self, unique_id, rank, world, root=0):
+        """adsp_bcast_spectrum_rank: this process is rank `rank` of `world` (one process per GPU); every rank calls it with
+        the 128 bytes rank 0 drew with rccl_unique_id().  Afterwards every engine runs the root's filter."""
+        uid = bytes(unique_id)
+        if len(uid) != _capi.ADSP_RCCL_UNIQUE_ID_BYTES:
+            raise ValueError(f"unique_id must be {_capi.ADSP_RCCL_UNIQUE_ID_BYTES} bytes")
+        _capi.check(self._lib.adsp_bcast_spectrum_rank(self._h, uid, int(rank), int(world), int(root)))
+        self.spectrum = self.get_spectrum()
+
     def set_accumulate(self, mode=True):
         """0/False overwrite the output buffer; 1/True add to what it holds (later parts of a partitioned FIR, a mix
         bus); 2 add and clip the sum to [-1, 1] (the last engine of a MixSignals bus, Utility.py:51-72)."""
@@ -233,7 +249,30 @@ def broadcast_filter(engines, root=0):
     arr = (ctypes.c_void_p * len(engines))(*[e._h for e in engines])
     _capi.check(lib.adsp_bcast_spectrum(arr, len(engines), int(root)))
     for e in engines:
-        e.fir, e.spectrum = engines[root].fir, engines[root].spectrum
+        e.fir, e.spectrum = engines[root].fir, e.get_spectrum()  # each engine's own copy, as the collective left it
+
+
+def rccl_unique_id():
+    """128 bytes from ncclGetUniqueId (rank 0 of a one-process-per-GPU job hands them to the other ranks)."""
+    buf = ctypes.create_string_buffer(_capi.ADSP_RCCL_UNIQUE_ID_BYTES)
+    _capi.check(_capi.load().adsp_rccl_unique_id(buf))
+    return buf.raw
+
+
+class ClockProbe:
+    """Shader clock while a workload runs: a one-lane kernel on `stream` (a side stream) counts shader cycles over
+    `microseconds` of the constant 100 MHz clock; read() waits for it and returns MHz."""
+
+    def __init__(self, device, microseconds, stream):
+        self._lib, self._device, self._stream = _capi.load(), int(device), stream
+        self._res = ctypes.c_void_p(None)
+        _capi.check(self._lib.adsp_clock_probe_launch(self._device, float(microseconds), _ptr(stream), ctypes.byref(self._res)))
+
+    def read(self):
+        mhz = ctypes.c_double(0.0)
+        _capi.check(self._lib.adsp_clock_probe_read(self._device, _ptr(self._stream), self._res, ctypes.byref(mhz)))
+        self._res = ctypes.c_void_p(None)
+        return mhz.value
 
 
 def rccl_version():

@@ -133,3 +133,67 @@ def test_local_bank_shards_channels_over_devices_in_one_process():
             ref = o.direct_stream_convolution(taps, x[:, c].reshape(-1), n)
             assert np.abs(y[:, c].reshape(-1) - ref).max() <= 1e-5 * np.abs(ref).max()
         bank.close()
+
+
+# ---- round 4: the collective behind the C ABI (adsp_bcast_spectrum_rank) - host logic only, no GPU ---------------------
+def _uid_worker(rank, world, path, q):
+    from pyaudiodsptools_amd import dist
+    uid = dist.exchange_unique_id(rank, world, lambda: bytes(range(128)), path=path, timeout=60.0)
+    q.put((rank, uid))
+    if rank == 0:  # rank 0 removes the file when it exits; in a real job the collective that follows keeps it alive until
+        import time  # every rank has joined - here it simply lingers
+        time.sleep(5.0)
+
+
+def test_unique_id_exchange_through_a_file_two_processes(tmp_path):
+    """exchange_unique_id: rank 0 draws the 128 bytes and publishes them atomically, rank 1 (started FIRST, so it has to
+    wait) picks them up; one exchange per process."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    path = str(tmp_path / "rccl_id")
+    p1 = ctx.Process(target=_uid_worker, args=(1, 2, path, q))
+    p1.start()
+    import time
+    time.sleep(0.3)
+    p0 = ctx.Process(target=_uid_worker, args=(0, 2, path, q))
+    p0.start()
+    got = dict(q.get(timeout=60) for _ in range(2))
+    p0.join(30)
+    p1.join(30)
+    assert got[0] == got[1] == bytes(range(128))
+
+
+class _FakeAbiEngine:
+    """Stand-in for FirEngine on a box without a GPU: records what the bank does with it."""
+    calls = []
+
+    def __init__(self, fir, channels=1, device=0, ring_slots=0, **kw):
+        self.fir, self.channels, self.kw = fir, channels, kw
+        self.spectrum = None
+
+    def bcast_rank(self, uid, rank, world, root=0):
+        _FakeAbiEngine.calls.append((bytes(uid), rank, world, root, self.channels))
+        self.spectrum = np.arange(4, dtype=np.float32)
+
+    def close(self):
+        self.closed = True
+
+
+def test_sharded_bank_abi_carrier_host_logic(monkeypatch):
+    """carrier="abi": the bank builds its engine first, fetches the job's id once and calls bcast_rank; no
+    torch.distributed involved."""
+    from pyaudiodsptools_amd import FirStream, design, dist
+    import pyaudiodsptools_amd.engine as engine_mod
+    monkeypatch.setattr(dist, "_job_unique_id", None)
+    monkeypatch.setattr(engine_mod, "rccl_unique_id", lambda: b"\x07" * 128)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("RANK", raising=False)
+    _FakeAbiEngine.calls.clear()
+    fir = FirStream(design.lowcut_kernel(300, 44100, 512), 512)
+    bank = dist.ShardedFirBank(fir, 10, device=0, engine_factory=_FakeAbiEngine, carrier="abi", optimize_for="batch")
+    assert bank.carrier == "abi" and bank.engine.channels == 10 and bank.engine.kw == {"optimize_for": "batch"}
+    assert _FakeAbiEngine.calls == [(b"\x07" * 128, 0, 1, 0, 10)]
+    assert np.array_equal(bank.spectrum, np.arange(4, dtype=np.float32))
+    with pytest.raises(ValueError):
+        dist.ShardedFirBank(fir, 10, engine_factory=_FakeAbiEngine, carrier="mpi")

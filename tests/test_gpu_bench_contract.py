@@ -39,6 +39,15 @@ def test_default_line_has_everything_the_driver_reads():
     assert c["kind"] == "port" and c["unit"] == "Msamples/s" and c["cores"] >= 1 and c["value"] > 0 and len(c["variants_msamples_s"]) == 4
     assert d["stream"]["value"] > 0 and d["latency"]["numpy_api_apply_us_per_call"] > 0
     assert sum(1 for ln in lines if ln.lstrip().startswith("{")) == 1  # exactly one JSON line
+    # SURVEY 8d statistics (round 4): five timed regions of exactly K steps, `value` is the median run, all runs are listed
+    rr = d["runs"]
+    assert rr["n"] == 5 and rr["statistic"] == "median" and len(rr["value_msamples_s"]) == 5 and len(rr["ms_per_step"]) == 5
+    assert rr["min"] <= rr["median"] <= rr["max"] and abs(rr["median"] - d["value"]) <= 1e-3 * d["value"]
+    assert sorted(rr["value_msamples_s"])[2] == rr["median"] and len(rr["shader_mhz"]) == 5
+    assert all(m is None or 500.0 < m < 3000.0 for m in rr["shader_mhz"]) and any(m is not None for m in rr["shader_mhz"])
+    # the timed output is parity-checked after the timed region (float64 direct sum on the GPU, 1e-5 like every parity test)
+    assert d["parity_checked"] is True and 0.0 <= d["max_rel_err"] <= 1e-5
+    assert d["parity"]["channels"] >= 16 and d["parity"]["samples"] >= 16 * 12 * 4096 and d["parity"]["launch"] >= 1
 
 
 def test_other_workloads_and_the_rccl_path_print_the_same_line():

@@ -1,0 +1,250 @@
+"""Round 4: the instantiation bench.py times, pinned at the timed size; full-size resident launches across ring
+laps; bench.py --gpus N with no launcher; the per-rank RCCL collective behind the ABI; chunk sizes that are not multiples
+of 4; the live (persistent) ring consumer; library-pipelined ring steps.  Run with -m gpu on MI355X."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_parity, seeded_stream
+from test_gpu_parity import assert_all_channels_match_exact, oracle_channels
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def adsp():
+    import pyaudiodsptools_amd as pkg
+    from pyaudiodsptools_amd import _capi
+    assert _capi.device_count() >= 1, "no GPU visible: the HIP path cannot run (no CPU fallback by design)"
+    return pkg
+
+
+def orc():
+    from oracle import fftfilter_oracle as o
+    return o
+
+
+def _copy_fn():
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    return hip.hipMemcpyAsync
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 1. The kernel instantiation the headline is quoted on - the BATCH geometry (4N transform on the M = 8192 plan, 3.5 N kept,
+#    non-temporal loads, one launch over many chunks) - at the timed channel counts, every sample of every channel.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("config,channels,make_taps", [
+    ("config2", 4096, lambda o, fs, n: o.lowcut_taps(800, fs, n)),     # bench.py's default workload (BASELINE configs[1])
+    ("config4", 8192, lambda o, fs, n: o.highcut_taps(8000, fs, n)),   # per-GPU shape of BASELINE configs[3]
+])
+def test_batch_geometry_at_the_timed_size_every_sample(adsp, config, channels, make_taps):
+    """Engines built exactly as bench.py's Runner builds them (optimize_for="batch": F = 4N on Plan<8192, 32, ..., MINW 4>,
+    14336 of 16384 samples kept), 14 chunks = two whole tiles in ONE adsp_apply_device launch (EffectFFTFilter.py:125-151 /
+    :49-75 for every channel and chunk at once): every output sample of every channel against the float64 direct sum on the
+    GPU, 32 channels (every XCD residue, first and last workgroups) against the oracle's direct_stream_convolution, the
+    impulse response == the taps, silence stays silence, and the same stream in two launches (history carried in the ring
+    across launches of this geometry) equals the one-launch result."""
+    import torch
+    from pyaudiodsptools_amd import FirEngine, FirStream
+    o = orc()
+    n, fs, steps = 4096, 44100, 14
+    taps = make_taps(o, fs, n)
+    fir = FirStream(taps, n)
+    eng = FirEngine(fir, channels=channels, device=0, ring_slots=0, fft_mult=0, sample_format="f32", optimize_for="batch")
+    assert eng.geometry.fft_size == 4 * n and eng.block_outputs == 14336 and eng.plan["complex_points"] == 8192
+    assert eng.real_spectrum
+    g = torch.Generator(device="cuda").manual_seed(2024 + channels)
+    x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=g)
+    x[:, 0] = 0
+    x[0, 0, 4095] = 1.0   # channel 0: unit impulse on the last sample of chunk 0
+    x[:, 1] = 0           # channel 1: silence
+    y = torch.full_like(x, float("nan"))
+    s = torch.cuda.current_stream().cuda_stream
+    eng.apply_device(x, y, steps, s)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(y).all())
+    assert_all_channels_match_exact(adsp, fir, x, y, f"{config} batch geometry")
+    yh, xh = y.cpu().numpy(), x.cpu().numpy()
+    assert not yh[:, 1].any()
+    d = n // 4 - 1
+    imp = yh[:, 0].reshape(-1)
+    start = n - d + 4095  # out[tau] = sum c[t] s[tau - N + d - t]
+    assert np.abs(imp[start:start + len(taps)] - taps).max() <= 1e-5 * np.abs(taps).max()
+    assert np.abs(np.delete(imp, np.arange(start, start + len(taps)))).max() <= 2e-6
+    for c in oracle_channels(channels):
+        assert_parity(yh[:, c].reshape(-1), o.direct_stream_convolution(taps, xh[:, c].reshape(-1), n), what=f"{config} batch ch {c}")
+    # two launches of one tile each == one launch of two tiles (the ring carries the history between launches)
+    eng.reset()
+    y2 = torch.empty_like(x)
+    eng.apply_device(x[:7], y2[:7], 7, s)
+    eng.apply_device(x[7:], y2[7:], 7, s)
+    torch.cuda.synchronize()
+    assert float((y2 - y).abs().max()) <= 2e-6
+    eng.close()
+
+
+def test_resident_launches_full_size_across_ring_laps(adsp):
+    """Config 3 at full size (4096 channels x 512 samples, CreateEQ3BandFFT: EffectEQ3BandFFT.py:156-211) through RESIDENT
+    launches of 128 steps over more than three laps of the ring, every lap carrying different data (a stale cache line of an
+    earlier lap would be a wrong sample), the producer a real device copy into the slot: every output sample of every
+    channel against the float64 direct sum."""
+    import torch
+    from pyaudiodsptools_amd import FirEngine, FirStream, design
+    n, fs, channels, per = 512, 44100, 4096, 128
+    fir = FirStream(design.eq3_composite(100, 2, 700, -4, 8000, 5, fs, n), n)
+    hist = design.overlap_save_geometry(fir, 0, "stream").history_chunks
+    slots = per + hist + 7                      # a ring the launches lap quickly: 7 launches = 896 steps = 6.5 laps
+    launches = 7
+    steps = per * launches
+    eng = FirEngine(fir, channels=channels, ring_slots=slots)
+    g = torch.Generator(device="cuda").manual_seed(99)
+    x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=g)
+    y = torch.full_like(x, float("nan"))
+    cons, prod = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    copy = _copy_fn()
+    k = 0
+    for launch in range(launches):
+        # the producer may run at most ring_slots - history steps ahead of what has been handed to consumer launches
+        for _ in range(per):
+            slot = eng.ring_produce_begin(prod)
+            assert copy(slot, x[k].data_ptr(), channels * n * 4, 3, prod.cuda_stream) == 0
+            k += 1
+        eng.ring_produce_end(prod)
+        eng.apply_ring_resident(y[launch * per:(launch + 1) * per], per, cons)
+    torch.cuda.synchronize()
+    assert not eng.ring_resident_timed_out()
+    assert bool(torch.isfinite(y).all())
+    assert_all_channels_match_exact(adsp, fir, x, y, "config3 resident launches over 6.5 ring laps")
+    eng.close()
+
+
+def test_resident_launch_table_outlives_eight_pending_launches(adsp):
+    """a large ring consumed by many SMALL resident launches keeps more than eight of them in flight; the
+    producer that laps the ring must still wait for the queued launch that has yet to read the slot it overwrites.  A slow
+    consumer stream (blocked behind a long exact-engine kernel) makes the race deterministic."""
+    import torch
+    from pyaudiodsptools_amd import FirEngine, FirStream, design
+    n, fs, channels = 512, 44100, 64
+    fir = FirStream(design.lowcut_kernel(300, fs, n), n)
+    hist = design.overlap_save_geometry(fir, 0, "stream").history_chunks
+    slots, per = 40, 2
+    laps = 3
+    steps = (slots - hist) // per * per * laps
+    eng = FirEngine(fir, channels=channels, ring_slots=slots)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=g)
+    y = torch.full_like(x, float("nan"))
+    cons, prod = torch.cuda.Stream(), torch.cuda.Stream()
+    # something slow at the head of the consumer stream: the resident launches queue up behind it
+    slow_fir = FirStream(np.random.default_rng(0).standard_normal(4000) / 100, 4096)
+    ex = adsp.ExactFirEngine(slow_fir, channels=2048)
+    big = torch.empty((8, 2048, 4096), device="cuda").uniform_(-1, 1, generator=g)
+    big_out = torch.empty_like(big)
+    torch.cuda.synchronize()
+    ex.apply_device(big, big_out, 8, cons.cuda_stream)
+    copy = _copy_fn()
+    k = 0
+    while k < steps:
+        for _ in range(per):
+            slot = eng.ring_produce_begin(prod)
+            assert copy(slot, x[k].data_ptr(), channels * n * 4, 3, prod.cuda_stream) == 0
+            k += 1
+        eng.ring_produce_end(prod)
+        eng.apply_ring_resident(y[k - per:k], per, cons)
+    torch.cuda.synchronize()
+    assert not eng.ring_resident_timed_out()
+    ex2 = adsp.ExactFirEngine(fir, channels=channels)
+    t = torch.empty_like(x)
+    ex2.apply_device(x, t, steps, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(y).all())
+    assert float((y - t).abs().max()) <= 1e-5 * float(t.abs().max())
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 2. bench.py --gpus N with no launcher; the collective behind the ABI for one process per GPU
+# ---------------------------------------------------------------------------------------------------------------------
+def test_bench_gpus2_without_a_launcher_reexecutes_itself():
+    """plain `python3 bench.py --gpus 2` (no torchrun on the command line, WORLD_SIZE unset) must produce the
+    N = 2 line: bench.py re-executes itself under torch.distributed.run.  Both ranks share the box's one GPU (test hook)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(ADSP_BENCH_SINGLE_DEVICE="1", ADSP_BENCH_SMALL="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm-ms", "20", "--runs", "3"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "weak" and "re-executed" in d["launcher"]
+    assert d["spectrum_checksum"]["equal_on_all_ranks"] is True
+    assert d["parity_checked"] is True and d["max_rel_err"] <= 1e-5 and d["runs"]["n"] == 3
+    cfgs = d["configs"]
+    assert set(cfgs) >= {"config4_highcut_8192ch_x_4096", "config5_chain_4096ch_x_8192_96k"}
+    for c in cfgs.values():
+        assert c["value"] > 0 and c["n_gpus"] == 2 and c["roofline_frac"] > 0 and c["parity_max_rel_err"] <= 1e-5
+
+
+def test_bench_single_process_line_carries_the_multi_gpu_keys():
+    """--single-process (adsp_bcast_spectrum, ncclCommInitAll): with one GPU a world of one; the keys of the N > 1 line are
+    there (ranks_seen, spectrum_checksum from adsp_get_spectrum)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--single-process", "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--prewarm-ms", "20", "--no-cpu-baseline", "--no-latency", "--no-stream-extra", "--chunks-per-step", "7", "--channels", "512",
+           "--runs", "3"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    d = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d["ranks_seen"] == 1 and d["spectrum_checksum"]["equal_on_all_ranks"] is True
+    assert d["spectrum_carrier"].startswith("adsp_bcast_spectrum") and d["parity_checked"] is True and d["max_rel_err"] <= 1e-5
+
+
+@pytest.mark.parametrize("fmt", ["f32", "s16_f64"])
+def test_bcast_spectrum_rank_world_of_one_real_engine(adsp, fmt):
+    """adsp_bcast_spectrum_rank (ncclCommInitRank behind the ABI) at world size 1 - all a one-GPU box can
+    prove: id from adsp_rccl_unique_id, header + spectrum broadcast, the engine rebuilds its tables from the buffer the
+    collective ran on (float64 spectra travel as float64), output parity afterwards; a filter change reuses the cached
+    communicator; the sharded bank drives the same path with carrier="abi"."""
+    import torch
+    from pyaudiodsptools_amd import FirEngine, FirStream, design, dist
+    from pyaudiodsptools_amd.engine import rccl_unique_id
+    n, fs, channels, steps = 1024, 48000, 6, 5
+    fir = FirStream(design.lowcut_kernel(300, fs, n), n)
+    other = FirStream(design.highcut_kernel(5000, fs, n), n)
+    uid = rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    eng = FirEngine(other, channels=channels, sample_format=fmt)
+    eng.set_fir(fir)
+    before = eng.get_spectrum().copy()
+    eng.bcast_rank(uid, 0, 1, 0)
+    assert np.array_equal(eng.get_spectrum(), before)
+    rng = np.random.default_rng(3)
+    if fmt == "f32":
+        x = rng.uniform(-1, 1, (steps, channels, n)).astype(np.float32)
+    else:
+        x = rng.integers(-20000, 20000, (steps, channels, n)).astype(np.int16)
+    y = eng.apply_host(x)
+    ex = adsp.ExactFirEngine(fir, channels=channels, sample_format="f32" if fmt == "f32" else "s16")
+    t = ex.apply_host(x)
+    if fmt == "f32":
+        assert np.abs(y - t).max() <= 1e-5 * np.abs(t).max()
+    else:
+        diff = np.abs(y.astype(np.int32) - t.astype(np.int32))  # the exact-FFT engine kept its float64 tables through the
+        assert diff.max() <= 1 and (diff > 0).sum() <= 2           # collective: a float32 spectrum would differ on ~0.2 % of the samples
+    eng.set_fir(other)              # a filter change: second broadcast on the cached communicator
+    eng.bcast_rank(uid, 0, 1, 0)
+    with pytest.raises(adsp._capi.AdspError):
+        eng.bcast_rank(uid, 1, 1, 0)   # rank out of range
+    eng.close()
+    if fmt == "f32":
+        bank = dist.ShardedFirBank(fir, channels, device=0, carrier="abi")
+        assert bank.carrier == "abi" and bank.engine.channels == channels
+        yb = bank.engine.apply_host(x)
+        assert np.abs(yb - t).max() <= 1e-5 * np.abs(t).max()
+        bank.engine.close()
