@@ -85,13 +85,16 @@ typedef struct adsp_engine adsp_engine; /* opaque.  Engines (and delay lines, sc
  */
 typedef struct adsp_config {
     int device_id;       /* HIP device ordinal */
-    int chunk_size;      /* N: samples per channel per step; any multiple of 4, >= 16 */
+    int chunk_size;      /* N: samples per channel per step; any length >= 4 (the reference takes any chunk_size: EffectFFTFilter.py:22).
+                            Multiples of 4 from 16 up move 16 bytes per access; other lengths run the generic kernel's dword-access
+                            form (float32 engines only, no fused effect) */
     int n_channels;      /* C: independent mono channels held by this engine */
     int fft_size;        /* F: real transform length, power of two in 128..32768.  N a power of two in 64..8192 with
                             F = 2N or 4N selects the specialised kernels (chunk boundaries known at compile time);
                             anything else runs the generic-geometry kernel */
     int history_chunks;  /* past chunks the window can reach (1..ADSP_MAX_HISTORY) */
-    int lookback;        /* see above; 0 < lookback <= history_chunks*N; multiple of N/4 (specialised) or 4 (generic) */
+    int lookback;        /* see above; 0 < lookback <= history_chunks*N; multiple of N/4 (specialised) or 4 (generic; any value
+                            when the chunk size is not a multiple of 4) */
     int out_offset;      /* see above; multiple of N/4 (specialised) or 4*threads_per_transform (generic) */
     int ring_slots;      /* input ring length (>= history_chunks+1); 0 = 2*history_chunks, which lets the ring
                             update of multi-step launches run on a side stream beside the kernel */
@@ -291,6 +294,48 @@ ADSP_API int adsp_ring_produce_end(adsp_engine* engine, void* stream);
 ADSP_API int adsp_apply_ring_resident(adsp_engine* engine, void* d_out, int n_steps, void* stream);
 ADSP_API int adsp_ring_resident_timeout(adsp_engine* engine, double milliseconds);
 ADSP_API int adsp_ring_resident_status(adsp_engine* engine, int* timed_out);
+
+/* Live sessions (round 4): the real-time call pattern of the reference (a chunk arrives, apply() runs, the next chunk arrives:
+ * Example3.py:20-34; config 3 = CreateEQ3BandFFT on 2048 stereo pairs of 512-sample chunks, EffectEQ3BandFFT.py:156-211) as ONE
+ * persistent launch.  adsp_live_start launches it on `stream`: one workgroup per channel group plus a relay workgroup, ALL
+ * resident at once (refused with ADSP_ERR_ARG when the engine has more channel groups than the GPU holds of this kernel), each
+ * looping over the steps of its channel group.  A step is consumed as soon as it is PUBLISHED; its N outputs per channel go to
+ * slot (step % out_slots) of d_out [out_slots][C][N].  The history the next window needs stays in registers, so every input
+ * sample is read from memory once (8 bytes of traffic per sample); the new chunk is read with system-scope loads and the
+ * outputs are written through, so the session may outlive any number of ring laps and readers on other streams / the host see
+ * the outputs once the progress count says so.
+ *   producer, per step (one host thread):
+ *     adsp_live_slot(engine, &d_slot)        ring slot [C][N] of the next step; ADSP_ERR_STATE "ring full" while the session is
+ *                                            ring_slots - history_chunks steps behind (poll adsp_live_progress / adsp_live_wait)
+ *     ... fill d_slot ...
+ *     adsp_live_publish_host(engine)         the data is complete and visible (blocking copy, or the producer's stream was
+ *                                            synchronised): ONE plain store to a host-mapped word - no HIP call, no command on
+ *                                            any queue; the relay workgroup forwards it to the device word the workers poll
+ *     adsp_live_publish_stream(engine, s)    or: a one-lane kernel enqueued on stream s behind the commands that fill the slot
+ *                                            bumps the device word itself (device-side producers may also do that from their
+ *                                            own kernels: adsp_live_device_words)
+ *   consumer side: adsp_live_progress (steps every channel group has completed, outputs in memory; a host-mapped word, no HIP
+ *   call), adsp_live_wait (spins on it), adsp_live_stop (ends the session once every published step is consumed, synchronises
+ *   `stream`, advances the engine's ring by the steps consumed - per-step calls may follow).
+ * A workgroup that waits longer than the step time-out (adsp_live_configure, default 1000 ms, 0 = for ever) gives up and the
+ * session ends; adsp_live_stop then returns ADSP_ERR_STATE.  Use an explicitly created non-blocking stream for the session
+ * (work on the NULL stream would wait for it).  Available for float32 engines in the stream geometry (power-of-two chunk 128 ..
+ * 4096, fft_size = 2 x chunk_size) with lookback 5/4 N (the cut filters) or 7/4 N (the 3-band EQ); no fused effect.
+ * load_mode: how the new chunk is read - 2 system scope (default), 1 non-temporal, 0 plain (tuning A/B only: a plain load may
+ * hit a cache line of an earlier ring lap). */
+ADSP_API int adsp_live_configure(adsp_engine* engine, double step_timeout_ms, int load_mode);
+ADSP_API int adsp_live_start(adsp_engine* engine, void* d_out, int out_slots, unsigned max_steps, void* stream);
+ADSP_API int adsp_live_slot(adsp_engine* engine, void** d_slot);
+ADSP_API int adsp_live_publish_host(adsp_engine* engine);
+ADSP_API int adsp_live_publish_stream(adsp_engine* engine, void* stream);
+/* benchmark / soak helper: a data-less producer in a native loop - takes and publishes the next n_steps slots one by one
+ * (whatever they hold is the input), through a one-lane kernel per step on `stream` (use_stream != 0) or through host stores,
+ * waiting for ring space where the session lags */
+ADSP_API int adsp_live_publish_run(adsp_engine* engine, unsigned n_steps, int use_stream, void* stream);
+ADSP_API int adsp_live_progress(adsp_engine* engine, unsigned* steps_done);
+ADSP_API int adsp_live_wait(adsp_engine* engine, unsigned steps, double timeout_ms);
+ADSP_API int adsp_live_device_words(adsp_engine* engine, unsigned** d_published, unsigned** d_done);
+ADSP_API int adsp_live_stop(adsp_engine* engine, unsigned* steps_consumed);
 
 /* Drain the device and forget the per-step ordering events.  Needed around hipGraph capture of ring steps: events
  * recorded inside a capture must not be waited on outside it (and vice versa), so call this before the capture begins

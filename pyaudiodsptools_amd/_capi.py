@@ -115,6 +115,16 @@ SIGNATURES = {
     "adsp_apply_ring_resident": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "adsp_ring_resident_timeout": (ctypes.c_int, [_engine_p, ctypes.c_double]),
     "adsp_ring_resident_status": (ctypes.c_int, [_engine_p, _c_int_p]),
+    "adsp_live_configure": (ctypes.c_int, [_engine_p, ctypes.c_double, ctypes.c_int]),
+    "adsp_live_start": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_void_p]),
+    "adsp_live_slot": (ctypes.c_int, [_engine_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "adsp_live_publish_host": (ctypes.c_int, [_engine_p]),
+    "adsp_live_publish_stream": (ctypes.c_int, [_engine_p, ctypes.c_void_p]),
+    "adsp_live_publish_run": (ctypes.c_int, [_engine_p, ctypes.c_uint, ctypes.c_int, ctypes.c_void_p]),
+    "adsp_live_progress": (ctypes.c_int, [_engine_p, ctypes.POINTER(ctypes.c_uint)]),
+    "adsp_live_wait": (ctypes.c_int, [_engine_p, ctypes.c_uint, ctypes.c_double]),
+    "adsp_live_device_words": (ctypes.c_int, [_engine_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]),
+    "adsp_live_stop": (ctypes.c_int, [_engine_p, ctypes.POINTER(ctypes.c_uint)]),
     "adsp_bcast_spectrum": (ctypes.c_int, [ctypes.POINTER(_engine_p), ctypes.c_int, ctypes.c_int]),
     "adsp_rccl_version": (ctypes.c_int, [_c_int_p]),
     "adsp_rccl_unique_id": (ctypes.c_int, [ctypes.c_char_p]),

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <utility>
 #include <vector>
@@ -163,10 +164,16 @@ int ilog2(int v) {
 
 // Two kinds of geometry: "specialised" (chunk a power of two in 64..8192, F = 2N or 4N: chunk boundaries are
 // compile-time constants in the kernel) and "generic" (any chunk divisible by 4, any supported power-of-two F).
+// ... and, within the generic kind, "unaligned" chunks (not a multiple of 4, or shorter than 16 samples: the reference takes any
+// chunk_size): float32 samples moved one dword at a time.
+bool unaligned_chunk(int N) { return N % 4 != 0 || N < 16; }
+
 int check_geometry(int N, int F, int fmt, const PlanInfo** out, bool* generic) {
     if (fmt != ADSP_FORMAT_F32 && fmt != ADSP_FORMAT_S16 && fmt != ADSP_FORMAT_S16_F64)
         return fail(ADSP_ERR_ARG, "sample_format %d: need ADSP_FORMAT_F32, ADSP_FORMAT_S16 or ADSP_FORMAT_S16_F64", fmt);
-    if (N < 16 || N % 4) return fail(ADSP_ERR_ARG, "chunk_size %d: need a multiple of 4, >= 16", N);
+    if (N < 4) return fail(ADSP_ERR_ARG, "chunk_size %d: need at least 4 samples", N);
+    if (unaligned_chunk(N) && fmt != ADSP_FORMAT_F32)
+        return fail(ADSP_ERR_ARG, "chunk_size %d: int16 engines need a multiple of 4, >= 16 (float32 engines take any chunk_size >= 4)", N);
     const bool three = F % 3 == 0 && is_pow2(F / 3);  // 3 * 2^k: the 1.5 N windows of the specialised kernels only
     if (!(is_pow2(F) || three) || F < 128 || F > 32768)
         return fail(ADSP_ERR_ARG, "fft_size %d: need a power of two in 128..32768 (or 1.5 x a power-of-two chunk that has a plan)", F);
@@ -174,6 +181,7 @@ int check_geometry(int N, int F, int fmt, const PlanInfo** out, bool* generic) {
     if (three && !special) return fail(ADSP_ERR_ARG, "fft_size %d = 3 * 2^k is only available as 1.5 x chunk_size", F);
     const PlanInfo* p = special ? find_plan(F / 2, 4 * F / N, fmt) : find_plan_any_fn(F / 2, fmt);
     if (!p) return fail(ADSP_ERR_ARG, "no kernel plan for %d complex points", F / 2);
+    if (unaligned_chunk(N) && !p->launch_unaligned) return fail(ADSP_ERR_STATE, "internal: no dword-access kernel for %d complex points", F / 2);
     if (out) *out = p;
     if (generic) *generic = !special;
     return ADSP_OK;
@@ -281,6 +289,7 @@ struct adsp_engine {
     float epi_p[3];
     int accumulate;   // 0 overwrite the output, 1 add to it (partitioned FIRs, mix bus), 2 add and clip to [-1, 1]
     bool generic;  // generic-geometry kernel (chunk not a power of two / F not 2N or 4N)
+    bool unaligned;  // ... its dword-access form (chunk not a multiple of 4, or < 16 samples)
     char* ring;    // [ring_slots][C][N] samples of cfg.sample_format
     int ring_pos;  // slot of the most recent chunk
     void* tw;     // real4 / real2 tables: float for the float kernels, double for ADSP_FORMAT_S16_F64 engines
@@ -350,6 +359,23 @@ struct adsp_engine {
     bool seq_by_copy;         // hipStreamWriteValue32 is not available: publications are 4-byte copies from pinned memory
     unsigned* pin_seq;        // pinned source values of such copies (kSeqPinned of them, reused round-robin)
     unsigned long long resident_timeout_ticks;
+    // live session (adsp_live_*): one persistent launch consumes ring steps as they are published
+    struct Live {
+        bool active = false;
+        const adsp::LivePlanInfo* plan = nullptr;
+        unsigned* d_words = nullptr;      // fine-grained device memory: [0] seq [1] done [2] stop [3] fail [4 .. 4 + ncg) progress
+        size_t d_words_n = 0;
+        unsigned* h_words = nullptr;      // pinned, device-mapped host memory: [0] host_seq [1] host_done [2] host_stop
+        unsigned* h_words_dev = nullptr;  // its device address
+        unsigned published = 0;           // steps published to the session so far
+        unsigned pending = 0;             // slots handed out by adsp_live_slot since the last publication
+        unsigned max_steps = 0;
+        int out_slots = 0;
+        int ncg = 0;
+        hipStream_t stream = nullptr;
+        int load_mode = 2;
+        double timeout_ms = 1000.0;
+    } live;
     hipStream_t copy_stream;  // ring update of multi-step launches runs beside the kernel
     hipEvent_t ev_in_ready, ev_copy_done;
     bool copy_pending;
@@ -549,7 +575,7 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
         }
         HIP_TRY(hipEventRecord(ev.first, stream));
     }
-    HIP_TRY(e->generic ? pl.launch_generic(a, (int)grid, stream) : pl.launch(a, (int)grid, stream));
+    HIP_TRY(e->unaligned ? pl.launch_unaligned(a, (int)grid, stream) : e->generic ? pl.launch_generic(a, (int)grid, stream) : pl.launch(a, (int)grid, stream));
     if (e->want_kernel_event) HIP_TRY(hipEventRecord(e->ev_kernel, stream));
     if (e->timing) {
         HIP_TRY(hipEventRecord(ev.second, stream));
@@ -562,8 +588,12 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
 
 // ------------------------------------------------------------------------------------------
 #define ADSP_NOT_RESIDENT(e)                                                                                              \
+    if ((e)->live.active) return fail(ADSP_ERR_STATE, "a live session owns the ring (adsp_live_start): call adsp_live_stop first");  \
     if ((e)->resident_mode)                                                                                                \
         return fail(ADSP_ERR_STATE, "the ring is in resident mode (adsp_ring_produce_* / adsp_apply_ring_resident): call adsp_ring_reset_order first")
+
+#define ADSP_NOT_LIVE(e) \
+    if ((e)->live.active) return fail(ADSP_ERR_STATE, "a live session is running (adsp_live_start): call adsp_live_stop first")
 
 extern "C" {
 
@@ -623,7 +653,7 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     } else {
         // generic geometry: 16-byte accesses need everything on the time axis to be a multiple of 4 samples; kept
         // ranges are whole register segments (2T samples)
-        if (cfg->lookback <= 0 || cfg->lookback > cfg->history_chunks * N || cfg->lookback % 4)
+        if (cfg->lookback <= 0 || cfg->lookback > cfg->history_chunks * N || (cfg->lookback % 4 && !unaligned_chunk(N)))
             return fail(ADSP_ERR_ARG, "lookback %d must be in (0, history_chunks*N] and a multiple of 4", cfg->lookback);
         if (cfg->out_offset < 0 || cfg->out_offset % (2 * T2) || cfg->out_offset + 2 * T2 > F)
             return fail(ADSP_ERR_ARG, "out_offset %d must be a multiple of %d with out_offset + %d <= F", cfg->out_offset, 2 * T2, 2 * T2);
@@ -647,6 +677,7 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     e->M = F / 2;
     e->logN = ilog2(N);
     e->generic = generic;
+    e->unaligned = generic && unaligned_chunk(N);
     e->accumulate = 0;
     e->epi_op = 0;
     e->lfo_len = 0;
@@ -713,7 +744,7 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
     };
     if ((rc = set_device(e))) return bail(rc);
     hipError_t err;
-    if ((err = (generic ? pl->prepare_generic() : pl->prepare())) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(err)));
+    if ((err = (e->unaligned ? pl->prepare_unaligned() : generic ? pl->prepare_generic() : pl->prepare())) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(err)));
     const size_t ring_bytes = (size_t)slots * e->plane_bytes();
     if ((err = hipMalloc(&e->ring, ring_bytes)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc ring (%zu bytes): %s", ring_bytes, hipGetErrorString(err)));
     if ((err = hipMemset(e->ring, 0, ring_bytes)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMemset: %s", hipGetErrorString(err)));
@@ -764,6 +795,11 @@ int adsp_destroy(adsp_engine* e) {
     if (e->ev_pub) (void)hipEventDestroy(e->ev_pub);
     if (e->d_seq) (void)hipFree(e->d_seq);
     if (e->pin_seq) (void)hipHostFree(e->pin_seq);
+    if (e->live.h_words) {
+        e->live.h_words[2] = 1;  // (a session still running ends at its next poll; the device was drained above in any case)
+        (void)hipHostFree(e->live.h_words);
+    }
+    if (e->live.d_words) (void)hipFree(e->live.d_words);
     for (auto& st : e->ring_steps) {
         if (st.in) (void)hipEventDestroy(st.in);
         if (st.out) (void)hipEventDestroy(st.out);
@@ -779,6 +815,7 @@ int adsp_destroy(adsp_engine* e) {
 
 int adsp_set_spectrum(adsp_engine* e, const float* spectrum, int n_bins) {
     if (!e || !spectrum) return fail(ADSP_ERR_ARG, "NULL argument");
+    ADSP_NOT_LIVE(e);
     if (n_bins != e->M + 1) return fail(ADSP_ERR_ARG, "n_bins %d != fft_size/2+1 = %d", n_bins, e->M + 1);
     int rc = set_device(e);
     if (rc) return rc;
@@ -789,6 +826,7 @@ int adsp_set_spectrum(adsp_engine* e, const float* spectrum, int n_bins) {
 
 int adsp_set_spectrum_f64(adsp_engine* e, const double* spectrum, int n_bins) {
     if (!e || !spectrum) return fail(ADSP_ERR_ARG, "NULL argument");
+    ADSP_NOT_LIVE(e);
     if (n_bins != e->M + 1) return fail(ADSP_ERR_ARG, "n_bins %d != fft_size/2+1 = %d", n_bins, e->M + 1);
     int rc = set_device(e);
     if (rc) return rc;
@@ -799,6 +837,7 @@ int adsp_set_spectrum_f64(adsp_engine* e, const double* spectrum, int n_bins) {
 
 int adsp_set_spectrum_async(adsp_engine* e, const float* spectrum, int n_bins, void* stream) {
     if (!e || !spectrum) return fail(ADSP_ERR_ARG, "NULL argument");
+    ADSP_NOT_LIVE(e);
     if (n_bins != e->M + 1) return fail(ADSP_ERR_ARG, "n_bins %d != fft_size/2+1 = %d", n_bins, e->M + 1);
     int rc = set_device(e);
     if (rc) return rc;
@@ -808,6 +847,7 @@ int adsp_set_spectrum_async(adsp_engine* e, const float* spectrum, int n_bins, v
 
 int adsp_set_spectrum_device(adsp_engine* e, const float* d_spectrum, int n_bins, void* stream) {
     if (!e || !d_spectrum) return fail(ADSP_ERR_ARG, "NULL argument");
+    ADSP_NOT_LIVE(e);
     if (n_bins != e->M + 1) return fail(ADSP_ERR_ARG, "n_bins %d != fft_size/2+1 = %d", n_bins, e->M + 1);
     int rc = set_device(e);
     if (rc) return rc;
@@ -990,6 +1030,8 @@ int adsp_set_block_outputs(adsp_engine* e, int v) {
 
 namespace {
 int prepare_twin(adsp_engine* e) {
+    if (e->unaligned) return fail(ADSP_ERR_ARG, "chunk_size %d is not a multiple of 4 (or < 16): fused effects and the clipping mix bus need an aligned chunk size - "
+                                  "run the effect as its own pass (adsp_effect_device)", e->cfg.chunk_size);
     if (!e->plan_epi) return fail(ADSP_ERR_STATE, "no effect kernel for this (tuning) plan");
     if (!e->epi_prepared) {
         int rc = set_device(e);
@@ -1246,6 +1288,7 @@ int ring_order_producer(adsp_engine* e, hipStream_t stream) {
 
 int adsp_reset(adsp_engine* e) {
     if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    ADSP_NOT_LIVE(e);
     int rc = set_device(e);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
@@ -1358,6 +1401,7 @@ int adsp_ring_acquire(adsp_engine* e, void** d_slot) {
 
 int adsp_ring_reset_order(adsp_engine* e) {
     if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    ADSP_NOT_LIVE(e);
     int rc = set_device(e);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
@@ -1520,6 +1564,276 @@ int adsp_apply_ring_resident(adsp_engine* e, void* d_out, int n_steps, void* str
     return ADSP_OK;
 }
 
+// ---- live sessions --------------------------------------------------------------------------------------------------
+namespace {
+int live_find_plan(adsp_engine* e, const adsp::LivePlanInfo** out) {
+    const adsp_config& c = e->cfg;
+    if (e->generic || c.sample_format != ADSP_FORMAT_F32 || c.fft_size != 2 * c.chunk_size)
+        return fail(ADSP_ERR_ARG, "live sessions run the stream geometry of float32 engines: power-of-two chunk, fft_size = 2 x chunk_size");
+    if (e->epi_op != 0 || e->accumulate != 0) return fail(ADSP_ERR_STATE, "live sessions take no fused effect and no accumulating output");
+    const int lq = c.lookback / (c.chunk_size / 4);
+    int n = 0;
+    const adsp::LivePlanInfo* tab = adsp::live_plans(&n);
+    for (int i = 0; i < n; ++i)
+        if (tab[i].M == e->M && tab[i].LQ == lq) {
+            *out = &tab[i];
+            return ADSP_OK;
+        }
+    return fail(ADSP_ERR_ARG, "no live kernel for chunk %d with lookback %d (= %d quarter chunks): built for chunks 128 .. 4096 with lookback 5/4 N "
+                "(cut filters) and 7/4 N (3-band EQ)", c.chunk_size, c.lookback, lq);
+}
+}  // namespace
+
+int adsp_live_configure(adsp_engine* e, double step_timeout_ms, int load_mode) {
+    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    if (e->live.active) return fail(ADSP_ERR_STATE, "a live session is running");
+    if (!(step_timeout_ms >= 0.0) || step_timeout_ms > 3.6e6) return fail(ADSP_ERR_ARG, "time-out must be in [0, 3.6e6] ms (0 = wait for ever)");
+    if (load_mode < 0 || load_mode > 2) return fail(ADSP_ERR_ARG, "load_mode: 0 plain, 1 non-temporal, 2 system-scope loads");
+    e->live.timeout_ms = step_timeout_ms;
+    e->live.load_mode = load_mode;
+    return ADSP_OK;
+}
+
+int adsp_live_start(adsp_engine* e, void* d_out, int out_slots, unsigned max_steps, void* stream_v) {
+    if (!e || !d_out) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (!e->have_spectrum) return fail(ADSP_ERR_STATE, "adsp_set_spectrum has not been called");
+    if (out_slots < 1 || max_steps < 1) return fail(ADSP_ERR_ARG, "out_slots and max_steps must be positive");
+    ADSP_NOT_RESIDENT(e);
+    if (e->multi_stream) return fail(ADSP_ERR_STATE, "ring steps are in flight on several streams: call adsp_ring_reset_order first");
+    int rc = set_device(e);
+    if (rc) return rc;
+    const adsp::LivePlanInfo* lp = nullptr;
+    if ((rc = live_find_plan(e, &lp))) return rc;
+    adsp_engine::Live& L = e->live;
+    const adsp_config& c = e->cfg;
+    const int ncg = (c.n_channels + lp->CPB - 1) / lp->CPB;
+    // every workgroup of the session must be resident at once: a waiting workgroup that kept another from being dispatched
+    // would wait for ever.  The occupancy API may answer one block per CU too many near an SGPR edge (MI355X_MICROARCH.md):
+    // one block per CU is left as margin.
+    int per_cu = 0, cus = 0;
+    HIP_TRY(lp->capacity(&per_cu));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device_id));
+    const long long room = (long long)(per_cu > 1 ? per_cu - 1 : per_cu) * cus;
+    if ((long long)ncg + 1 > room)
+        return fail(ADSP_ERR_ARG, "a live session needs all %d workgroups resident at once, this device holds %lld of this kernel (%d per CU, one kept "
+                    "as margin): use fewer channels per engine", ncg + 1, room, per_cu);
+    if (!L.h_words) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&L.h_words), 16 * sizeof(unsigned), hipHostMallocMapped));
+        void* d = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&d, L.h_words, 0));
+        L.h_words_dev = static_cast<unsigned*>(d);
+    }
+    const size_t n_words = 4 + (size_t)ncg;
+    if (L.d_words_n < n_words) {
+        if (L.d_words) (void)hipFree(L.d_words);
+        L.d_words = nullptr;
+        L.d_words_n = 0;
+        void* p = nullptr;
+        if (hipExtMallocWithFlags(&p, n_words * sizeof(unsigned), hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(hipMalloc(&p, n_words * sizeof(unsigned)));
+        }
+        L.d_words = static_cast<unsigned*>(p);
+        L.d_words_n = n_words;
+    }
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (e->copy_pending) {
+        HIP_TRY(hipStreamWaitEvent(stream, e->ev_copy_done, 0));
+        e->copy_pending = false;
+    }
+    for (int i = 0; i < 16; ++i) L.h_words[i] = 0;
+    HIP_TRY(hipMemsetAsync(L.d_words, 0, n_words * sizeof(unsigned), stream));
+    adsp::LiveArgs la;
+    memset(&la, 0, sizeof la);
+    adsp::KernelArgs& a = la.k;
+    a.ring = e->ring;
+    a.tw = e->tw;
+    a.pair = e->pair;
+    a.pair0 = e->pair0;
+    a.zeros = e->zeros;
+    a.ring_pos = e->ring_pos;
+    a.ring_slots = c.ring_slots;
+    a.C = c.n_channels;
+    a.n_steps = 1;
+    a.V = c.chunk_size;
+    a.nblk = 1;
+    a.lookback = c.lookback;
+    a.j0 = c.out_offset;
+    a.ncg = ncg;
+    a.N = c.chunk_size;
+    a.nh = c.history_chunks;
+    a.inv_n = 1.0f / (float)c.chunk_size;
+    a.real_spec = e->real_spec ? 1 : 0;
+    a.win_pairs = e->plan->P / 2;
+    la.out = d_out;
+    la.out_slots = out_slots;
+    la.first_pub = 0;
+    la.max_steps = max_steps;
+    la.seq = L.d_words;
+    la.done = L.d_words + 1;
+    la.stop = L.d_words + 2;
+    la.fail = L.d_words + 3;
+    la.progress = L.d_words + 4;
+    la.host_seq = L.h_words_dev;
+    la.host_done = L.h_words_dev + 1;
+    la.host_stop = L.h_words_dev + 2;
+    la.timeout = (unsigned long long)(L.timeout_ms * 1e5);  // 100 MHz ticks
+    la.load_mode = L.load_mode;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if (e->timing) {
+        if (!e->free_ev.empty()) {
+            ev = e->free_ev.back();
+            e->free_ev.pop_back();
+        } else {
+            HIP_TRY(hipEventCreate(&ev.first));
+            HIP_TRY(hipEventCreate(&ev.second));
+        }
+        HIP_TRY(hipEventRecord(ev.first, stream));
+    }
+    HIP_TRY(lp->launch(la, ncg + 1, stream));
+    if (e->timing) {
+        HIP_TRY(hipEventRecord(ev.second, stream));
+        e->timed.push_back(ev);
+    }
+    L.active = true;
+    L.plan = lp;
+    L.published = L.pending = 0;
+    L.max_steps = max_steps;
+    L.out_slots = out_slots;
+    L.ncg = ncg;
+    L.stream = stream;
+    return ADSP_OK;
+}
+
+int adsp_live_slot(adsp_engine* e, void** d_slot) {
+    if (!e || !d_slot) return fail(ADSP_ERR_ARG, "NULL argument");
+    adsp_engine::Live& L = e->live;
+    if (!L.active) return fail(ADSP_ERR_STATE, "no live session (adsp_live_start)");
+    const unsigned q = L.published + L.pending;  // session index of the step this slot will carry
+    if (q >= L.max_steps) return fail(ADSP_ERR_STATE, "the session ends after %u steps", L.max_steps);
+    // the slot last carried step q - S (or, for the first lap, a history chunk the kernel loads when it starts): it is free
+    // once every workgroup is past step q - (S - history)
+    const int S = e->cfg.ring_slots, usable = S - e->cfg.history_chunks;
+    const unsigned done = *static_cast<volatile unsigned*>(L.h_words + 1);
+    if ((long long)q - usable + 1 > (long long)done)
+        return fail(ADSP_ERR_STATE, "ring full: step %u would overwrite a slot the session has not consumed yet (%u steps done, %d usable slots)", q, done, usable);
+    const int slot = (int)(((long long)e->ring_pos + 1 + q) % S);
+    *d_slot = e->ring + (size_t)slot * e->plane_bytes();
+    L.pending += 1;
+    return ADSP_OK;
+}
+
+int adsp_live_publish_host(adsp_engine* e) {
+    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    adsp_engine::Live& L = e->live;
+    if (!L.active || L.pending < 1) return fail(ADSP_ERR_STATE, "adsp_live_publish without adsp_live_slot");
+    L.published += L.pending;
+    L.pending = 0;
+    __atomic_store_n(L.h_words, L.published, __ATOMIC_RELEASE);  // a plain store to mapped memory: no HIP call, no queue
+    return ADSP_OK;
+}
+
+int adsp_live_publish_stream(adsp_engine* e, void* stream_v) {
+    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    adsp_engine::Live& L = e->live;
+    if (!L.active || L.pending < 1) return fail(ADSP_ERR_STATE, "adsp_live_publish without adsp_live_slot");
+    int rc = set_device(e);
+    if (rc) return rc;
+    L.published += L.pending;
+    L.pending = 0;
+    HIP_TRY(adsp::live_publish(L.d_words, L.published, (hipStream_t)stream_v));
+    return ADSP_OK;
+}
+
+// A data-less producer in a tight native loop (benchmarks, soak tests): the next n_steps slots are taken and published ONE BY
+// ONE - whatever the slots hold is the input - waiting for ring space where the session lags.  use_stream: publish through a
+// one-lane kernel on `stream` per step; otherwise through host stores.
+int adsp_live_publish_run(adsp_engine* e, unsigned n_steps, int use_stream, void* stream_v) {
+    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    adsp_engine::Live& L = e->live;
+    if (!L.active) return fail(ADSP_ERR_STATE, "no live session (adsp_live_start)");
+    const int usable = e->cfg.ring_slots - e->cfg.history_chunks;
+    for (unsigned k = 0; k < n_steps; ++k) {
+        const unsigned q = L.published + L.pending;
+        if (q >= L.max_steps) return fail(ADSP_ERR_STATE, "the session ends after %u steps", L.max_steps);
+        if ((long long)q - usable + 1 > (long long)__atomic_load_n(L.h_words + 1, __ATOMIC_ACQUIRE)) {
+            const int rc = adsp_live_wait(e, (unsigned)(q - usable + 1), 20000.0);
+            if (rc) return rc;
+        }
+        void* slot = nullptr;
+        int rc = adsp_live_slot(e, &slot);
+        if (rc) return rc;
+        rc = use_stream ? adsp_live_publish_stream(e, stream_v) : adsp_live_publish_host(e);
+        if (rc) return rc;
+    }
+    return ADSP_OK;
+}
+
+int adsp_live_progress(adsp_engine* e, unsigned* steps_done) {
+    if (!e || !steps_done) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (!e->live.h_words) return fail(ADSP_ERR_STATE, "no live session has been started");
+    *steps_done = __atomic_load_n(e->live.h_words + 1, __ATOMIC_ACQUIRE);
+    return ADSP_OK;
+}
+
+int adsp_live_wait(adsp_engine* e, unsigned steps, double timeout_ms) {
+    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    adsp_engine::Live& L = e->live;
+    if (!L.active) return fail(ADSP_ERR_STATE, "no live session (adsp_live_start)");
+    if (steps > L.max_steps) return fail(ADSP_ERR_ARG, "the session ends after %u steps", L.max_steps);
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    unsigned spins = 0;
+    while (__atomic_load_n(L.h_words + 1, __ATOMIC_ACQUIRE) < steps) {
+        if ((++spins & 0x3ff) == 0) {
+            timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            const double ms = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+            if (ms > timeout_ms) return fail(ADSP_ERR_STATE, "live session: %u of %u steps done after %.1f ms", __atomic_load_n(L.h_words + 1, __ATOMIC_ACQUIRE), steps, ms);
+            if (hipStreamQuery(L.stream) == hipSuccess && __atomic_load_n(L.h_words + 1, __ATOMIC_ACQUIRE) < steps)
+                return fail(ADSP_ERR_STATE, "the live session has ended (time-out of a workgroup, or stopped) with %u of %u steps done",
+                            __atomic_load_n(L.h_words + 1, __ATOMIC_ACQUIRE), steps);
+            (void)hipGetLastError();
+        }
+    }
+    return ADSP_OK;
+}
+
+int adsp_live_device_words(adsp_engine* e, unsigned** d_seq, unsigned** d_done) {
+    if (!e || !d_seq || !d_done) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (!e->live.active) return fail(ADSP_ERR_STATE, "no live session (adsp_live_start)");
+    *d_seq = e->live.d_words;
+    *d_done = e->live.d_words + 1;
+    return ADSP_OK;
+}
+
+int adsp_live_stop(adsp_engine* e, unsigned* steps_consumed) {
+    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    adsp_engine::Live& L = e->live;
+    if (!L.active) return fail(ADSP_ERR_STATE, "no live session (adsp_live_start)");
+    int rc = set_device(e);
+    if (rc) return rc;
+    __atomic_store_n(L.h_words + 2, 1u, __ATOMIC_RELEASE);
+    HIP_TRY(hipStreamSynchronize(L.stream));
+    std::vector<unsigned> w(4 + (size_t)L.ncg);
+    HIP_TRY(hipMemcpy(w.data(), L.d_words, w.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+    unsigned done = 0xffffffffu;
+    for (int i = 0; i < L.ncg; ++i) done = w[4 + i] < done ? w[4 + i] : done;
+    const bool timed_out = w[3] != 0;
+    L.active = false;
+    // the ring moves on by the steps EVERY channel group consumed (after a time-out some may be further: adsp_reset then)
+    const int S = e->cfg.ring_slots;
+    e->ring_pos = (int)(((long long)e->ring_pos + done) % S);
+    e->step_no += done;
+    e->have_last_stream = true;
+    e->last_stream = L.stream;
+    if (steps_consumed) *steps_consumed = done;
+    if (timed_out) return fail(ADSP_ERR_STATE, "live session: a workgroup gave up waiting for step %u after %.0f ms (adsp_live_configure); "
+                               "the engine's history is undefined: adsp_reset", done, L.timeout_ms);
+    return ADSP_OK;
+}
+
+
 int adsp_ring_resident_timeout(adsp_engine* e, double milliseconds) {
     if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
     if (!(milliseconds > 0.0) || milliseconds > 60000.0) return fail(ADSP_ERR_ARG, "time-out must be in (0, 60000] ms");
@@ -1613,6 +1927,7 @@ int adsp_apply_host(adsp_engine* e, const void* in, void* out, int n_steps) {
 
 int adsp_get_state(adsp_engine* e, void* host_history) {
     if (!e || !host_history) return fail(ADSP_ERR_ARG, "NULL argument");
+    ADSP_NOT_LIVE(e);
     int rc = set_device(e);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
@@ -1629,6 +1944,7 @@ int adsp_get_state(adsp_engine* e, void* host_history) {
 
 int adsp_set_state(adsp_engine* e, const void* host_history) {
     if (!e || !host_history) return fail(ADSP_ERR_ARG, "NULL argument");
+    ADSP_NOT_LIVE(e);
     int rc = set_device(e);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());

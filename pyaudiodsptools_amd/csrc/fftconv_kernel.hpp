@@ -109,6 +109,29 @@ struct KernelArgs {
     unsigned long long seq_timeout;  // in ticks of the constant 100 MHz clock (wall_clock64)
 };
 
+// Live sessions (adsp_live_*, round 4): ONE persistent launch consumes ring steps as they are published, for as long as the
+// host wants.  Every workgroup owns its channel group for the whole session and keeps the `lookback` samples of history the
+// next window needs IN REGISTERS, so each input sample is read from memory exactly once; the grid is no larger than the GPU
+// holds (the host checks), so a workgroup that waits for a publication never blocks the dispatch of another.
+struct LiveArgs {
+    KernelArgs k;                  // ring, tables, C, ncg, lookback, j0, ring_pos / ring_slots: as for a per-step launch (k.out unused)
+    void* out;                     // output ring [out_slots][C][N]: step s of this session goes to slot s % out_slots
+    int out_slots;
+    unsigned first_pub;            // value of the sequence word when every step before this session had been published
+    unsigned max_steps;            // the session ends after this many steps (or when stopped)
+    unsigned* seq;                 // device word (fine-grained): steps published so far; device-side producers bump it themselves
+    const volatile unsigned* host_seq;  // host-mapped word a HOST producer bumps with a plain store (no HIP call); the relay workgroup
+                                   // forwards it into *seq
+    unsigned* progress;            // [ncg] device words: steps this workgroup has completed (outputs written through to memory)
+    unsigned* done;                // device word: min over progress[] (maintained by the relay workgroup)
+    volatile unsigned* host_done;  // the same, host-mapped: the host reads it without a HIP call
+    const volatile unsigned* host_stop;  // host-mapped: non-zero = end the session once every published step is consumed
+    unsigned* stop;                // device copy of it (relay), polled by waiting workgroups
+    unsigned* fail;                // set by a workgroup that gave up waiting (time-out)
+    unsigned long long timeout;    // ticks of the 100 MHz clock a workgroup waits for ONE step (0 = for ever)
+    int load_mode;                 // 0 plain, 1 non-temporal, 2 system-scope (sc0 sc1) loads of the new chunk (tuning; default 2)
+};
+
 #define ADSP_F64 0
 #include "fftconv_core.inc"
 #undef ADSP_F64

@@ -17,6 +17,16 @@ struct PlanInfo {
     // the same transform behind the generic-geometry kernel (any chunk size divisible by 4, FQ is ignored)
     hipError_t (*launch_generic)(const KernelArgs&, int grid, hipStream_t);
     hipError_t (*prepare_generic)();
+    // ... and for chunk sizes that are not multiples of 4 (dword accesses; float32 plain kernels only, nullptr otherwise)
+    hipError_t (*launch_unaligned)(const KernelArgs&, int grid, hipStream_t);
+    hipError_t (*prepare_unaligned)();
+};
+
+// one persistent kernel of the live sessions: M = N complex points (F = 2N), lookback LQ quarter chunks
+struct LivePlanInfo {
+    int M, CPB, LQ, T;
+    hipError_t (*launch)(const LiveArgs&, int grid, hipStream_t);
+    hipError_t (*capacity)(int* blocks_per_cu);  // sets the kernel's LDS attribute, asks the occupancy API
 };
 
 #include "plan_table_core.inc"
@@ -70,6 +80,8 @@ const PlanInfo* plans_f32(int* count);
 const PlanInfo* plans_s16(int* count);
 const PlanInfo* plans_f32_epi(int* count);  // same list, kernels with the fused output effect (float32 only)
 const PlanInfo* variants_f32(int* count);  // A/B alternatives, ADSP_PLAN_VARIANT=<n>
+const LivePlanInfo* live_plans(int* count);  // plans_live.hip
+hipError_t live_publish(unsigned* seq, unsigned value, hipStream_t s);
 const PlanInfo* plans_s16_f64(int* count);  // int16 samples, float64 arithmetic (namespace adsp::f64 kernels): plans_s16_f64.hip
 
 }  // namespace adsp

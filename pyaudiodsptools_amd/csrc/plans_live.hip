@@ -1,0 +1,52 @@
+// plans_live.hip - the persistent kernels of live sessions (adsp_live_*, fftconv_core.inc: fftconv_live_kernel): float32
+// samples, F = 2N transforms of the stream geometry, one instantiation per (chunk size, lookback in quarter chunks).
+// Lookback 5/4 N = the reference's cut filters (EffectFFTFilter.py), 7/4 N = its 3-band FFT EQ (EffectEQ3BandFFT.py).
+#include "plan_table.hpp"
+
+namespace {
+using namespace adsp;
+
+// device-side publication of the next step(s): enqueued on the producer's stream behind the commands that filled the slot
+__global__ void live_publish_kernel(unsigned* seq, unsigned value) {
+    __hip_atomic_fetch_max(seq, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <class PL, int CPB, int LQ>
+hipError_t live_launch(const LiveArgs& a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((fftconv_live_kernel<PL, CPB, 8, LQ>), dim3(grid), dim3(PL::T * CPB), (lds_bytes<PL, CPB>()), s, a);
+    return hipGetLastError();
+}
+
+template <class PL, int CPB, int LQ>
+hipError_t live_capacity(int* blocks_per_cu) {
+    const void* fn = reinterpret_cast<const void*>(&fftconv_live_kernel<PL, CPB, 8, LQ>);
+    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<PL, CPB>());
+    if (err != hipSuccess) return err;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, PL::T * CPB, lds_bytes<PL, CPB>());
+}
+
+template <class PL, int CPB, int LQ>
+constexpr LivePlanInfo make_live() {
+    return LivePlanInfo{PL::M, CPB, LQ, PL::T, &live_launch<PL, CPB, LQ>, &live_capacity<PL, CPB, LQ>};
+}
+
+#define ADSP_LIVE_FOR(LQ)                                              \
+    make_live<Plan<128, 16, 2, 16, 8, 1, 1>, 8, LQ>(),                 \
+    make_live<Plan<256, 16, 3, 4, 8, 8, 1>, 4, LQ>(),                  \
+    make_live<Plan<512, 16, 3, 16, 4, 8, 1>, 2, LQ>(),                 \
+    make_live<Plan<1024, 16, 3, 16, 8, 8, 1>, 1, LQ>(),                \
+    make_live<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, LQ>(),               \
+    make_live<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, LQ>()
+
+const LivePlanInfo kLive[] = {ADSP_LIVE_FOR(5), ADSP_LIVE_FOR(7)};
+}  // namespace
+
+const adsp::LivePlanInfo* adsp::live_plans(int* count) {
+    *count = sizeof(kLive) / sizeof(kLive[0]);
+    return kLive;
+}
+
+hipError_t adsp::live_publish(unsigned* seq, unsigned value, hipStream_t s) {
+    hipLaunchKernelGGL(live_publish_kernel, dim3(1), dim3(1), 0, s, seq, value);
+    return hipGetLastError();
+}

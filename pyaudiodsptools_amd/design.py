@@ -12,9 +12,12 @@ import numpy as np
 
 
 def filter_length(chunk_size):
-    """L = N//2 - 1 (EffectFFTFilter.py:22); d = (L-1)//2 is the look-ahead of the kept slice."""
+    """L = N//2 - 1 (EffectFFTFilter.py:22); d = L//2 is the look-ahead of the kept slice (the slice starts at N + L//2,
+    EffectFFTFilter.py:24: (L-1)/2 for the odd L every chunk size with N % 4 == 0 gives, L/2 for the even L of N = 30, 1002 ..)."""
     taps = int(chunk_size) // 2 - 1
-    return taps, (taps - 1) // 2
+    if taps < 1:
+        raise ValueError(f"chunk_size {chunk_size}: the reference's filter length N//2 - 1 must be at least 1")
+    return taps, taps // 2
 
 
 def _lowpass(cutoff_hz, fs, taps, window):
@@ -195,15 +198,18 @@ def _generic_geometry(fir: FirStream, fft_mult: int, optimize_for: str) -> Geome
     batch: the transform with the fewest flops per kept sample."""
     from . import _capi
     n, m, d_total = int(fir.chunk_size), len(fir.taps), fir.delay
-    if n < 16 or n % 4:
-        raise ValueError(f"chunk_size {n}: need a multiple of 4 (>= 16)")
+    if n < 4:
+        raise ValueError(f"chunk_size {n}: need at least 4 samples")
+    # chunk sizes that are not multiples of 4 (or shorter than 16) run on the kernel's dword-access form (round 4): nothing on
+    # the time axis has to be aligned there
+    align = 1 if (n % 4 or n < 16) else 4
     if d_total <= 0:
         raise ValueError("non-causal stream")
     centre = (m - 1) // 2
     symmetric = m % 2 == 1 and np.abs(fir.taps - fir.taps[::-1]).max() <= 1e-13 * np.abs(fir.taps).max()
     # a symmetric kernel centred on circular index 0 (real spectrum, see overlap_save_geometry) also needs less room
     # in front of the kept slice: (m-1)/2 wrapped taps instead of m-1
-    zero_phase = bool(symmetric and (d_total + centre) % 4 == 0)
+    zero_phase = bool(symmetric and (d_total + centre) % align == 0)
     best = None
     for log_f in range(7, 16):
         f = 1 << log_f
@@ -221,7 +227,7 @@ def _generic_geometry(fir: FirStream, fft_mult: int, optimize_for: str) -> Geome
         else:
             j0 = -(-(m + 2) // t2) * t2
             v = (f - j0) // t2 * t2
-            shift = (d_total + j0) % 4
+            shift = (d_total + j0) % align
         if v < t2:
             continue
         lookback = d_total + j0 - shift

@@ -226,6 +226,46 @@ class FirEngine:
         _capi.check(self._lib.adsp_ring_resident_status(self._h, ctypes.byref(v)))
         return bool(v.value)
 
+    # live sessions (include/adsp.h): ONE persistent launch consumes ring steps as they are published
+    def live_configure(self, step_timeout_ms=1000.0, load_mode=2):
+        _capi.check(self._lib.adsp_live_configure(self._h, float(step_timeout_ms), int(load_mode)))
+
+    def live_start(self, d_out, out_slots, max_steps, stream):
+        """d_out [out_slots, C, N]: step s of the session writes slot s % out_slots.  Use an explicitly created stream."""
+        _capi.check(self._lib.adsp_live_start(self._h, _ptr(d_out), int(out_slots), int(max_steps), _ptr(stream)))
+
+    def live_slot(self):
+        """Device address of the ring slot the next step's [C, N] batch goes to (AdspError 'ring full' while the session lags)."""
+        p = ctypes.c_void_p(None)
+        _capi.check(self._lib.adsp_live_slot(self._h, ctypes.byref(p)))
+        return p.value
+
+    def live_publish(self, stream=None):
+        """Publish every slot handed out since the last publication: with a stream, a one-lane kernel behind the commands that
+        filled them; without, a plain host store (the data must already be complete and visible)."""
+        if stream is None:
+            _capi.check(self._lib.adsp_live_publish_host(self._h))
+        else:
+            _capi.check(self._lib.adsp_live_publish_stream(self._h, _ptr(stream)))
+
+    def live_publish_run(self, n_steps, stream=None):
+        """A data-less producer in a native loop: publish the next n_steps slots one by one (bench / soak)."""
+        _capi.check(self._lib.adsp_live_publish_run(self._h, int(n_steps), 0 if stream is None else 1, _ptr(stream)))
+
+    def live_progress(self):
+        v = ctypes.c_uint(0)
+        _capi.check(self._lib.adsp_live_progress(self._h, ctypes.byref(v)))
+        return v.value
+
+    def live_wait(self, steps, timeout_ms=10000.0):
+        _capi.check(self._lib.adsp_live_wait(self._h, int(steps), float(timeout_ms)))
+
+    def live_stop(self):
+        """End the session (after every published step is consumed); returns the steps consumed."""
+        v = ctypes.c_uint(0)
+        _capi.check(self._lib.adsp_live_stop(self._h, ctypes.byref(v)))
+        return v.value
+
     def apply_ring(self, d_out, stream=None):
         _capi.check(self._lib.adsp_apply_ring(self._h, _ptr(d_out), _ptr(stream)))
 

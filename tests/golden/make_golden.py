@@ -51,7 +51,10 @@ def save(name, **arrays):
 
 
 def main():
-    meta = {"numpy": np.__version__}
+    meta = {"numpy": np.__version__,
+            "note_kat_example1_full": "kat_example1_full.npz (make_golden_example1_full.py) carries the reference's whole 16-bit mono test WAV "
+                                      "(TestFile16BitMono.wav, 264600 samples) as int16 PCM DATA - the input of the full Example1 run - next to "
+                                      "outputs of the reference; no source text of the reference is stored anywhere under tests/"}
 
     # ---- design kernels -------------------------------------------------------------
     design = {}
@@ -72,6 +75,15 @@ def main():
         design[tag + "_lowshelf"] = taps_of(dev.sinc_filter_lowshelf, dev.filter_length)
         design[tag + "_mid_lowpass"] = taps_of(dev.sinc_filter_mid_lowpass, dev.filter_length)
         design[tag + "_mid_highpass"] = taps_of(dev.sinc_filter_mid_highpass, dev.filter_length)
+    # even filter lengths (chunk sizes with N // 2 odd): the spectral inversion adds its 1 at (L - 1) // 2 = L/2 - 1
+    for fs, n, fc in [(48000, 1002, 500), (44100, 30, 3000)]:
+        ref.config.initialize(fs, n)
+        design[f"lowcut_{fs}_{n}_{fc}"] = taps_of(ref.CreateLowCutFilter(fc).sinc_filter, n // 2 - 1)
+        design[f"highcut_{fs}_{n}_{fc}"] = taps_of(ref.CreateHighCutFilter(fc).sinc_filter, n // 2 - 1)
+    ref.config.initialize(48000, 1002)
+    dev = ref.CreateEQ3BandFFT(250, -6, 1500, 3, 6000, -2.5)
+    for part in ("highshelf", "lowshelf", "mid_lowpass", "mid_highpass"):
+        design["eq_48000_1002_250_-6_1500_3_6000_-2.5_" + part] = taps_of(getattr(dev, "sinc_filter_" + part), dev.filter_length)
     # default-argument constructors (EffectFFTFilter.py:18 / :91)
     ref.config.initialize(44100, 512)
     design["highcut_default_44100_512"] = taps_of(ref.CreateHighCutFilter().sinc_filter, 255)
@@ -119,6 +131,23 @@ def main():
     kat["LC12000"] = run_device(ref.CreateLowCutFilter(120), stream(89, 3 * 12000), 12000)
     ref.config.initialize(44100, 20)
     kat["EQ20"] = run_device(ref.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), stream(90, 40 * 20), 20)
+    # chunk sizes that are NOT multiples of 4 (round 4): the reference takes any chunk_size; N // 2 odd gives an
+    # EVEN filter length (N = 30: 14 taps, N = 1002: 500), whose slice look-ahead L // 2 is one more than (L - 1) // 2
+    ref.config.initialize(44100, 30)
+    kat["LC30"] = run_device(ref.CreateLowCutFilter(3000), stream(93, 30 * 30), 30)
+    kat["HC30"] = run_device(ref.CreateHighCutFilter(8000), stream(94, 30 * 30), 30)
+    kat["EQ30"] = run_device(ref.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), stream(95, 30 * 30), 30)
+    ref.config.initialize(44100, 1001)
+    kat["LC1001"] = run_device(ref.CreateLowCutFilter(300), stream(96, 7 * 1001), 1001)
+    kat["EQ1001"] = run_device(ref.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), stream(97, 7 * 1001), 1001)
+    ref.config.initialize(48000, 1002)
+    kat["LC1002"] = run_device(ref.CreateLowCutFilter(500), stream(98, 7 * 1002), 1002)
+    kat["HC1002"] = run_device(ref.CreateHighCutFilter(9000), stream(99, 7 * 1002), 1002)
+    kat["EQ1002"] = run_device(ref.CreateEQ3BandFFT(250, -6, 1500, 3, 6000, -2.5), stream(100, 7 * 1002), 1002)
+    ref.config.initialize(44100, 6)   # two taps
+    kat["HC6"] = run_device(ref.CreateHighCutFilter(8000), stream(101, 50 * 6), 6)
+    ref.config.initialize(44100, 4410)  # 100 ms at 44.1 kHz: N % 4 == 2, 2204 taps
+    kat["LC4410"] = run_device(ref.CreateLowCutFilter(160), stream(102, 4 * 4410), 4410)
     # Example4's chunk size (88200 = 2 s at 44.1 kHz, 44099 taps): every 64th output sample of 3 chunks
     ref.config.initialize(44100, 88200)
     kat["LC88200_dec64"] = run_device(ref.CreateLowCutFilter(300), stream(91, 3 * 88200), 88200)[::64].copy()

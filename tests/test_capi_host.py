@@ -40,7 +40,9 @@ def test_plans_cover_supported_chunk_sizes():
     assert (d["complex_points"], d["points_per_thread"], d["threads_per_transform"], d["lds_bytes"]) == (3072, 48, 64, 3072 * 8 // 2)
     assert lib.adsp_plan_supported(512, 768) != 0 and lib.adsp_plan_supported(1000, 6144) != 0
     assert lib.adsp_plan_supported(32, 64) != 0       # ... of at least 128 points
-    assert lib.adsp_plan_supported(3002, 8192) != 0   # chunk must be a multiple of 4
+    assert lib.adsp_plan_supported(3002, 8192) == 0   # round 4: ANY chunk size >= 4 (not a multiple of 4: dword-access kernel)
+    assert lib.adsp_plan_supported(1001, 4096) == 0 and lib.adsp_plan_supported(30, 128) == 0 and lib.adsp_plan_supported(6, 128) == 0
+    assert lib.adsp_plan_supported(3, 128) != 0
     assert lib.adsp_plan_supported(3000, 8192) == 0   # generic geometry: any such chunk with any supported transform
     assert lib.adsp_plan_supported(44100, 32768) == 0
     assert b"chunk_size" in lib.adsp_last_error() or b"fft_size" in lib.adsp_last_error()
@@ -86,6 +88,14 @@ def test_design_matches_reference_kernels(golden):
     k = design.eq3_kernels(250, 1500, 6000, 48000, 1024)
     for band in ("highshelf", "lowshelf", "mid_lowpass", "mid_highpass"):
         assert np.abs(k[band] - g[f"eq_48000_1024_250_-6_1500_3_6000_-2.5_{band}"]).max() < 1e-12
+    # even filter lengths (N // 2 odd: N = 1002 -> 500 taps, N = 30 -> 14)
+    assert np.abs(design.lowcut_kernel(500, 48000, 1002) - g["lowcut_48000_1002_500"]).max() < 1e-12
+    assert np.abs(design.highcut_kernel(500, 48000, 1002) - g["highcut_48000_1002_500"]).max() < 1e-12
+    assert np.abs(design.lowcut_kernel(3000, 44100, 30) - g["lowcut_44100_30_3000"]).max() < 1e-12
+    k = design.eq3_kernels(250, 1500, 6000, 48000, 1002)
+    for band in ("highshelf", "lowshelf", "mid_lowpass", "mid_highpass"):
+        assert np.abs(k[band] - g[f"eq_48000_1002_250_-6_1500_3_6000_-2.5_{band}"]).max() < 1e-12
+    assert design.filter_length(1002) == (500, 250) and design.filter_length(4096) == (2047, 1023) and design.filter_length(30) == (14, 7)
     spec = design.reference_spectrum_3n(design.highcut_kernel(8000, 44100, 4096), 4096)
     assert abs(spec[1] - g["spot_B_H01"][1]) < 1e-12
 
@@ -97,7 +107,15 @@ def test_host_overlap_save_math_against_golden(golden):
     from conftest import assert_parity, seeded_stream
     cases = {"A": (design.lowcut_kernel(800, 44100, 4096), 4096, 1234, 6),
              "C": (design.eq3_composite(100, 2, 700, -4, 8000, 5, 44100, 512), 512, 1234, 6),
-             "HC256": (design.highcut_kernel(3000, 44100, 256), 256, 83, 9)}
+             "HC256": (design.highcut_kernel(3000, 44100, 256), 256, 83, 9),
+             # chunk sizes that are not multiples of 4: even filter lengths (look-ahead L // 2), generic geometry with nothing aligned
+             "LC30": (design.lowcut_kernel(3000, 44100, 30), 30, 93, 30),
+             "EQ30": (design.eq3_composite(100, 2, 700, -4, 8000, 5, 44100, 30), 30, 95, 30),
+             "LC1001": (design.lowcut_kernel(300, 44100, 1001), 1001, 96, 7),
+             "HC1002": (design.highcut_kernel(9000, 48000, 1002), 1002, 99, 7),
+             "EQ1002": (design.eq3_composite(250, -6, 1500, 3, 6000, -2.5, 48000, 1002), 1002, 100, 7),
+             "HC6": (design.highcut_kernel(8000, 44100, 6), 6, 101, 50),
+             "LC4410": (design.lowcut_kernel(160, 44100, 4410), 4410, 102, 4)}
     for name, (taps, n, seed, chunks) in cases.items():
         fir = design.FirStream(taps, n)
         geo = design.overlap_save_geometry(fir)

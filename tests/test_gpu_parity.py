@@ -42,6 +42,18 @@ KAT = {
     "HC1920": (lambda p: p.CreateHighCutFilter(9000), 48000, 1920, 88, 5),
     "LC12000": (lambda p: p.CreateLowCutFilter(120), 44100, 12000, 89, 3),
     "EQ20": (lambda p: p.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), 44100, 20, 90, 40),
+    # chunk sizes that are NOT multiples of 4 (round 4): the kernel's dword-access form; N // 2 odd gives an even
+    # filter length, whose slice look-ahead is L // 2 (EffectFFTFilter.py:22-25)
+    "LC30": (lambda p: p.CreateLowCutFilter(3000), 44100, 30, 93, 30),
+    "HC30": (lambda p: p.CreateHighCutFilter(8000), 44100, 30, 94, 30),
+    "EQ30": (lambda p: p.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), 44100, 30, 95, 30),
+    "LC1001": (lambda p: p.CreateLowCutFilter(300), 44100, 1001, 96, 7),
+    "EQ1001": (lambda p: p.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), 44100, 1001, 97, 7),
+    "LC1002": (lambda p: p.CreateLowCutFilter(500), 48000, 1002, 98, 7),
+    "HC1002": (lambda p: p.CreateHighCutFilter(9000), 48000, 1002, 99, 7),
+    "EQ1002": (lambda p: p.CreateEQ3BandFFT(250, -6, 1500, 3, 6000, -2.5), 48000, 1002, 100, 7),
+    "HC6": (lambda p: p.CreateHighCutFilter(8000), 44100, 6, 101, 50),
+    "LC4410": (lambda p: p.CreateLowCutFilter(160), 44100, 4410, 102, 4),
 }
 
 

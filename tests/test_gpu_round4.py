@@ -248,3 +248,227 @@ def test_bcast_spectrum_rank_world_of_one_real_engine(adsp, fmt):
         yb = bank.engine.apply_host(x)
         assert np.abs(yb - t).max() <= 1e-5 * np.abs(t).max()
         bank.engine.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 3. Chunk sizes that are not multiples of 4 (the reference's drop-in streams are in test_gpu_parity.KAT: LC30 .. LC4410)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,kind,channels", [(30, "eq", 5), (1001, "lowcut", 67), (1002, "highcut", 9), (1002, "eq", 33), (4410, "lowcut", 3),
+                                             (6, "highcut", 70), (13, "asym", 4), (2050, "asym", 11), (8, "lowcut", 2), (12, "eq", 3)])
+def test_unaligned_chunk_sizes_batches_vs_exact_engine(adsp, n, kind, channels):
+    """The dword-access kernel on [steps, channels, N] batches with N % 4 != 0 (or N < 16): ragged channel counts, per-step and
+    multi-step launches (stream and batch geometry), host buffers, accumulate mode, against the float64 direct sum."""
+    import torch
+    from pyaudiodsptools_amd import FirEngine, FirStream, design
+    fs, steps = 44100, 9
+    rng = np.random.default_rng(n + channels)
+    if kind == "lowcut":
+        fir = FirStream(design.lowcut_kernel(500, fs, n), n)
+    elif kind == "highcut":
+        fir = FirStream(design.highcut_kernel(6000, fs, n), n)
+    elif kind == "eq":
+        fir = FirStream(design.eq3_composite(100, 2, 700, -4, 8000, 5, fs, n), n)
+    else:  # an arbitrary asymmetric kernel with its own delay
+        m = max(2, n // 3)
+        fir = FirStream(rng.standard_normal(m) / np.sqrt(m), n, 1, min(n - 1, m // 2))
+    x = torch.from_numpy(rng.uniform(-1, 1, (steps, channels, n)).astype(np.float32)).cuda()
+    ex = adsp.ExactFirEngine(fir, channels=channels)
+    t = torch.empty_like(x)
+    s = torch.cuda.current_stream().cuda_stream
+    ex.apply_device(x, t, steps, s)
+    torch.cuda.synchronize()
+    scale = max(float(t.abs().max()), 0.1)
+    for mode in ("stream", "batch"):
+        eng = FirEngine(fir, channels=channels, optimize_for=mode)
+        y = torch.full_like(x, float("nan"))
+        for k in range(steps):                      # one launch per step
+            eng.apply_device(x[k], y[k], 1, s)
+        torch.cuda.synchronize()
+        assert float((y - t).abs().max()) <= 1e-5 * scale, (mode, "per step")
+        eng.reset()
+        y2 = torch.full_like(x, float("nan"))
+        eng.apply_device(x[:4], y2[:4], 4, s)       # multi-step launches, split unevenly
+        eng.apply_device(x[4:], y2[4:], steps - 4, s)
+        torch.cuda.synchronize()
+        assert float((y2 - t).abs().max()) <= 1e-5 * scale, (mode, "multi step")
+        eng.reset()
+        yh = eng.apply_host(x.cpu().numpy())         # host buffers
+        assert np.abs(yh - t.cpu().numpy()).max() <= 1e-5 * scale
+        eng.reset()
+        eng.set_accumulate(1)                        # add to what the buffer holds
+        y3 = torch.ones_like(x)
+        eng.apply_device(x, y3, steps, s)
+        torch.cuda.synchronize()
+        assert float((y3 - 1.0 - t).abs().max()) <= 2e-5 * scale
+        with pytest.raises(adsp._capi.AdspError):
+            eng.set_accumulate(2)                    # the clipping mix bus and fused effects need an aligned chunk size
+        eng.close()
+    with pytest.raises(adsp._capi.AdspError):
+        FirEngine(fir, channels=channels, sample_format="s16")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 4. Live sessions: one persistent launch, history in registers, publications without a command on any queue
+# ---------------------------------------------------------------------------------------------------------------------
+def _exact(adsp, fir, x):
+    import torch
+    ex = adsp.ExactFirEngine(fir, channels=x.shape[1])
+    t = torch.empty_like(x)
+    ex.apply_device(x, t, x.shape[0], torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ex.close()
+    return t
+
+
+def test_live_session_config3_full_size_producer_on_a_second_stream(adsp):
+    """config 3 at full size (4096 channels x 512 samples, CreateEQ3BandFFT - EffectEQ3BandFFT.py:156-211,
+    Example3.py:20-34) as ONE persistent launch with a LIVE producer: a second stream copies every chunk batch into its ring
+    slot and publishes it, step by step, while the session runs (it is launched before any input exists); the input ring is
+    lapped six times, every lap with different data.  No time-out; every output sample of every channel against the float64
+    direct sum."""
+    import torch
+    from pyaudiodsptools_amd import FirEngine, FirStream, design
+    n, fs, channels, steps = 512, 44100, 4096, 400
+    fir = FirStream(design.eq3_composite(100, 2, 700, -4, 8000, 5, fs, n), n)
+    hist = design.overlap_save_geometry(fir, 0, "stream").history_chunks
+    usable = 64
+    eng = FirEngine(fir, channels=channels, ring_slots=usable + hist)
+    g = torch.Generator(device="cuda").manual_seed(41)
+    x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=g)
+    y = torch.full_like(x, float("nan"))
+    cons, prod = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    copy = _copy_fn()
+    eng.live_configure(step_timeout_ms=5000.0)
+    eng.live_start(y, steps, steps, cons)
+    import time
+    time.sleep(0.02)
+    assert eng.live_progress() == 0 and not cons.query()   # resident, waiting for its first publication
+    for k in range(steps):
+        while True:
+            try:
+                slot = eng.live_slot()
+                break
+            except adsp._capi.AdspError as exc:            # the producer is a whole ring ahead: wait for the session
+                assert "ring full" in str(exc)
+                eng.live_wait(k - usable + 1, 10000.0)
+        assert copy(slot, x[k].data_ptr(), channels * n * 4, 3, prod.cuda_stream) == 0
+        eng.live_publish(prod)
+    eng.live_wait(steps, 20000.0)
+    assert eng.live_stop() == steps
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(y).all())
+    assert_all_channels_match_exact(adsp, fir, x, y, "config3 live session")
+    eng.close()
+
+
+@pytest.mark.parametrize("n,kind,channels", [(512, "lowcut", 70), (1024, "eq", 33), (128, "highcut", 1000), (256, "eq", 5), (2048, "lowcut", 40),
+                                             (4096, "eq", 24)])
+def test_live_session_host_publication_outputs_visible_while_it_runs(adsp, n, kind, channels):
+    """A HOST producer: blocking copy into the slot, then adsp_live_publish_host - one plain store to mapped memory, no HIP call.
+    After adsp_live_wait(k + 1) the outputs of step k are read from the 3-slot output ring by another stream WHILE the session
+    keeps running (write-through stores, progress word behind them), step by step against the float64 direct sum; ragged
+    channel counts, both lookbacks (5/4 N cut filters, 7/4 N EQ), every live plan size.  Afterwards the stream continues with
+    ordinary per-step calls: the ring carried the history."""
+    import torch
+    from pyaudiodsptools_amd import FirEngine, FirStream, design
+    fs, steps = 44100, 23
+    taps = {"lowcut": lambda: design.lowcut_kernel(500, fs, n), "highcut": lambda: design.highcut_kernel(6000, fs, n),
+            "eq": lambda: design.eq3_composite(100, 2, 700, -4, 8000, 5, fs, n)}[kind]()
+    fir = FirStream(taps, n)
+    eng = FirEngine(fir, channels=channels, ring_slots=7)
+    g = torch.Generator(device="cuda").manual_seed(n + channels)
+    x = torch.empty((steps + 3, channels, n), device="cuda").uniform_(-1, 1, generator=g)
+    t = _exact(adsp, fir, x)
+    scale = float(t.abs().max())
+    # two ordinary steps first: the session starts from a non-trivial history in the ring
+    y0 = torch.empty_like(x[:2])
+    s = torch.cuda.current_stream().cuda_stream
+    eng.apply_device(x[:2], y0, 2, s)
+    torch.cuda.synchronize()
+    assert float((y0 - t[:2]).abs().max()) <= 1e-5 * scale
+    out = torch.full((3, channels, n), float("nan"), device="cuda")
+    cons = torch.cuda.Stream()
+    copy = _copy_fn()
+    eng.live_start(out, 3, steps, cons)
+    with pytest.raises(adsp._capi.AdspError):
+        eng.apply_device(x[:1], y0[:1], 1, s)   # the session owns the ring
+    for k in range(steps):
+        slot = eng.live_slot()
+        assert copy(slot, x[2 + k].data_ptr(), channels * n * 4, 3, None) == 0
+        torch.cuda.current_stream().synchronize()     # the data is in the slot
+        eng.live_publish()                             # host store
+        eng.live_wait(k + 1, 10000.0)
+        got = out[k % 3].clone()                       # another stream reads while the session runs
+        torch.cuda.current_stream().synchronize()
+        err = float((got - t[2 + k]).abs().max())
+        assert err <= 1e-5 * scale, (k, err)
+    assert eng.live_progress() == steps
+    assert eng.live_stop() == steps
+    z = torch.empty((channels, n), device="cuda")
+    eng.apply_device(x[2 + steps], z, 1, s)            # the stream goes on with per-step calls
+    torch.cuda.synchronize()
+    assert float((z - t[2 + steps]).abs().max()) <= 1e-5 * scale
+    eng.close()
+
+
+def test_live_session_refusals_stop_and_time_out(adsp):
+    import time
+    import torch
+    from pyaudiodsptools_amd import FirEngine, FirStream, design
+    fs = 44100
+    fir = FirStream(design.lowcut_kernel(500, fs, 512), 512)
+    cons = torch.cuda.Stream()
+    out = torch.zeros((2, 8, 512), device="cuda")
+    # geometries without a live kernel: a 4N batch engine, a generic chunk size
+    eng = FirEngine(FirStream(design.lowcut_kernel(500, fs, 1024), 1024), channels=8, optimize_for="batch")
+    with pytest.raises(adsp._capi.AdspError):
+        eng.live_start(torch.zeros((2, 8, 1024), device="cuda"), 2, 4, cons)
+    eng.close()
+    eng = FirEngine(FirStream(design.lowcut_kernel(500, fs, 1000), 1000), channels=8)
+    with pytest.raises(adsp._capi.AdspError):
+        eng.live_start(torch.zeros((2, 8, 1000), device="cuda"), 2, 4, cons)
+    eng.close()
+    # more channel groups than the GPU holds at once
+    big = FirEngine(FirStream(design.lowcut_kernel(500, fs, 4096), 4096), channels=4096)
+    with pytest.raises(adsp._capi.AdspError) as ei:
+        big.live_start(torch.zeros((1, 4096, 4096), device="cuda"), 1, 4, cons)
+    assert "resident" in str(ei.value)
+    big.close()
+    eng = FirEngine(fir, channels=8, ring_slots=6)
+    with pytest.raises(adsp._capi.AdspError):
+        eng.live_slot()                                  # no session
+    # stop with nothing published: zero steps consumed, the engine is usable afterwards
+    eng.live_start(out, 2, 100, cons)
+    with pytest.raises(adsp._capi.AdspError):
+        eng.live_start(out, 2, 100, cons)
+    with pytest.raises(adsp._capi.AdspError):
+        eng.reset()
+    with pytest.raises(adsp._capi.AdspError):
+        eng.live_publish()                               # nothing handed out
+    time.sleep(0.01)
+    assert eng.live_stop() == 0
+    # ring full: ring_slots - history slots may be produced ahead
+    eng.live_configure(step_timeout_ms=60.0)
+    eng.live_start(out, 2, 100, cons)
+    for _ in range(4):
+        eng.live_slot()
+    with pytest.raises(adsp._capi.AdspError) as ei:
+        eng.live_slot()
+    assert "ring full" in str(ei.value)
+    # ... and a session whose producer never publishes gives up after the step time-out instead of holding the GPU for ever
+    t0 = time.time()
+    with pytest.raises(adsp._capi.AdspError) as ei:
+        eng.live_wait(1, 5000.0)
+    assert time.time() - t0 < 3.0 and ("ended" in str(ei.value) or "steps done" in str(ei.value))
+    with pytest.raises(adsp._capi.AdspError) as ei:
+        eng.live_stop()
+    assert "gave up" in str(ei.value)
+    eng.reset()
+    x = torch.empty((3, 8, 512), device="cuda").uniform_(-1, 1)
+    y = torch.empty_like(x)
+    eng.apply_device(x, y, 3, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    t = _exact(adsp, fir, x)
+    assert float((y - t).abs().max()) <= 1e-5 * float(t.abs().max())
+    eng.close()

@@ -30,6 +30,17 @@ KAT = {
     "HC1920": (lambda fs, n: orc.OracleHighCut(9000, fs, n), 48000, 1920, 88, 5),
     "LC12000": (lambda fs, n: orc.OracleLowCut(120, fs, n), 44100, 12000, 89, 3),
     "EQ20": (lambda fs, n: orc.OracleEQ3BandFFT(100, 2, 700, -4, 8000, 5, fs, n), 44100, 20, 90, 40),
+    # chunk sizes that are not multiples of 4 (round 4): N // 2 odd gives an EVEN filter length (look-ahead L // 2)
+    "LC30": (lambda fs, n: orc.OracleLowCut(3000, fs, n), 44100, 30, 93, 30),
+    "HC30": (lambda fs, n: orc.OracleHighCut(8000, fs, n), 44100, 30, 94, 30),
+    "EQ30": (lambda fs, n: orc.OracleEQ3BandFFT(100, 2, 700, -4, 8000, 5, fs, n), 44100, 30, 95, 30),
+    "LC1001": (lambda fs, n: orc.OracleLowCut(300, fs, n), 44100, 1001, 96, 7),
+    "EQ1001": (lambda fs, n: orc.OracleEQ3BandFFT(100, 2, 700, -4, 8000, 5, fs, n), 44100, 1001, 97, 7),
+    "LC1002": (lambda fs, n: orc.OracleLowCut(500, fs, n), 48000, 1002, 98, 7),
+    "HC1002": (lambda fs, n: orc.OracleHighCut(9000, fs, n), 48000, 1002, 99, 7),
+    "EQ1002": (lambda fs, n: orc.OracleEQ3BandFFT(250, -6, 1500, 3, 6000, -2.5, fs, n), 48000, 1002, 100, 7),
+    "HC6": (lambda fs, n: orc.OracleHighCut(8000, fs, n), 44100, 6, 101, 50),
+    "LC4410": (lambda fs, n: orc.OracleLowCut(160, fs, n), 44100, 4410, 102, 4),
 }
 SHA = {"A": "a77f6d09f062", "B": "5af354dacc5b", "C": "9084f1fbd924", "D": "e17160836e0f"}
 
@@ -164,13 +175,14 @@ def test_input_types(golden):
 
 
 # ---- independent ground truth: float64 direct convolution (no FFT) -----------------------------
-@pytest.mark.parametrize("name", ["A", "B", "C", "D", "HC256", "EQ128", "LC64", "EQ1024", "LC1000", "EQ1000", "EQ20"])
+@pytest.mark.parametrize("name", ["A", "B", "C", "D", "HC256", "EQ128", "LC64", "EQ1024", "LC1000", "EQ1000", "EQ20",
+                                  "LC30", "HC30", "EQ30", "LC1001", "EQ1001", "LC1002", "HC1002", "EQ1002", "HC6", "LC4410"])
 def test_direct_convolution_identity(golden, name):
     make, fs, n, seed, chunks = KAT[name]
     x = seeded_stream(seed, chunks * n)
     dev = make(fs, n)
     if isinstance(dev, orc.OracleEQ3BandFFT):
-        params = {"EQ1024": (250, -6, 1500, 3, 6000, -2.5)}.get(name, (100, 2, 700, -4, 8000, 5))
+        params = {"EQ1024": (250, -6, 1500, 3, 6000, -2.5), "EQ1002": (250, -6, 1500, 3, 6000, -2.5)}.get(name, (100, 2, 700, -4, 8000, 5))
         taps = orc.eq3_composite_taps(*params, fs, n)
     else:
         taps = np.fft.ifft(dev.spectrum).real[: n // 2 - 1]
