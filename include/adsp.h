@@ -257,6 +257,16 @@ ADSP_API int adsp_apply_device(adsp_engine* engine, const void* d_in, void* d_ou
 ADSP_API int adsp_ring_acquire(adsp_engine* engine, void** d_slot);
 ADSP_API int adsp_ring_acquire_stream(adsp_engine* engine, void** d_slot, void* stream);
 ADSP_API int adsp_apply_ring(adsp_engine* engine, void* d_out, void* stream);
+/* The same overlap without the caller juggling streams (round 4): adsp_ring_set_pipeline(engine, 2) makes the LIBRARY run step k
+ * on its own stream k % 2.  The caller keeps ONE stream: adsp_ring_acquire_stream(engine, &slot, stream) orders its producer after
+ * the kernels that still read the slot, the producer is enqueued on `stream`, adsp_apply_ring(engine, d_out, stream) records an
+ * event on `stream` (everything enqueued so far = the producer), lets the step's own stream wait for it and launches there; the
+ * per-step events above order the steps through the ring.  What changes for the caller: the outputs are NOT ordered on `stream`
+ * any more - adsp_ring_join(engine, stream) makes `stream` wait for every step issued so far (call it before `stream` reads
+ * d_out, or synchronise the device).  Needs ring_slots >= history_chunks + 2; depth 1 restores the default.  Measured on
+ * config 2's per-chunk pattern (4096 channels x 4096 samples, one launch per chunk): 44 us per step against 48.6 on one stream. */
+ADSP_API int adsp_ring_set_pipeline(adsp_engine* engine, int depth);
+ADSP_API int adsp_ring_join(adsp_engine* engine, void* stream);
 /* Resident ring launches: ONE launch consumes the next n_steps ring steps, and the workgroups of step k start as soon
  * as the producer side has PUBLISHED that step - consecutive steps overlap inside one grid, with no launch boundary
  * between them (per-step launches of small chunk batches spend a third of each step ramping up and draining: config 3,
@@ -321,6 +331,9 @@ ADSP_API int adsp_ring_resident_status(adsp_engine* engine, int* timed_out);
  * session ends; adsp_live_stop then returns ADSP_ERR_STATE.  Use an explicitly created non-blocking stream for the session
  * (work on the NULL stream would wait for it).  Available for float32 engines in the stream geometry (power-of-two chunk 128 ..
  * 4096, fft_size = 2 x chunk_size) with lookback 5/4 N (the cut filters) or 7/4 N (the 3-band EQ); no fused effect.
+ * While a session runs, anything that drains the whole device waits for it: hipDeviceSynchronize, and the set-up calls of this
+ * library that contain one (adsp_set_spectrum, adsp_reset, adsp_get_state / adsp_set_state, adsp_destroy of ANY engine on the
+ * device) - stop the session first, or do the set-up before it starts.
  * load_mode: how the new chunk is read - 2 system scope (default), 1 non-temporal, 0 plain (tuning A/B only: a plain load may
  * hit a cache line of an earlier ring lap). */
 ADSP_API int adsp_live_configure(adsp_engine* engine, double step_timeout_ms, int load_mode);

@@ -110,6 +110,8 @@ SIGNATURES = {
     "adsp_ring_acquire": (ctypes.c_int, [_engine_p, ctypes.POINTER(ctypes.c_void_p)]),
     "adsp_ring_acquire_stream": (ctypes.c_int, [_engine_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
     "adsp_ring_reset_order": (ctypes.c_int, [_engine_p]),
+    "adsp_ring_set_pipeline": (ctypes.c_int, [_engine_p, ctypes.c_int]),
+    "adsp_ring_join": (ctypes.c_int, [_engine_p, ctypes.c_void_p]),
     "adsp_ring_produce_begin": (ctypes.c_int, [_engine_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
     "adsp_ring_produce_end": (ctypes.c_int, [_engine_p, ctypes.c_void_p]),
     "adsp_apply_ring_resident": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),

@@ -359,6 +359,12 @@ struct adsp_engine {
     bool seq_by_copy;         // hipStreamWriteValue32 is not available: publications are 4-byte copies from pinned memory
     unsigned* pin_seq;        // pinned source values of such copies (kSeqPinned of them, reused round-robin)
     unsigned long long resident_timeout_ticks;
+    // pipelined ring steps (adsp_ring_set_pipeline): step k runs on the library's own stream k % depth, so consecutive launches
+    // overlap (the next one fills the CUs the previous one is draining); the caller's stream carries the producers only
+    int pipe_depth = 1;
+    hipStream_t pipe_stream[2] = {nullptr, nullptr};
+    hipEvent_t pipe_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    unsigned pipe_ev_next = 0;
     // live session (adsp_live_*): one persistent launch consumes ring steps as they are published
     struct Live {
         bool active = false;
@@ -771,6 +777,7 @@ int adsp_create(const adsp_config* cfg, adsp_engine** out_engine) {
 int adsp_destroy(adsp_engine* e) {
     if (!e) return ADSP_OK;
     (void)hipSetDevice(e->cfg.device_id);
+    if (e->live.h_words) __atomic_store_n(e->live.h_words + 2, 1u, __ATOMIC_RELEASE);  // a session still running ends at its next poll
     (void)hipDeviceSynchronize();
     if (e->ring) (void)hipFree(e->ring);
     if (e->tw) (void)hipFree(e->tw);
@@ -793,12 +800,13 @@ int adsp_destroy(adsp_engine* e) {
     for (auto& rl : e->resident_launches)
         if (rl.done) (void)hipEventDestroy(rl.done);
     if (e->ev_pub) (void)hipEventDestroy(e->ev_pub);
+    for (hipStream_t st : e->pipe_stream)
+        if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t ev : e->pipe_ev)
+        if (ev) (void)hipEventDestroy(ev);
     if (e->d_seq) (void)hipFree(e->d_seq);
     if (e->pin_seq) (void)hipHostFree(e->pin_seq);
-    if (e->live.h_words) {
-        e->live.h_words[2] = 1;  // (a session still running ends at its next poll; the device was drained above in any case)
-        (void)hipHostFree(e->live.h_words);
-    }
+    if (e->live.h_words) (void)hipHostFree(e->live.h_words);
     if (e->live.d_words) (void)hipFree(e->live.d_words);
     for (auto& st : e->ring_steps) {
         if (st.in) (void)hipEventDestroy(st.in);
@@ -1432,6 +1440,17 @@ int adsp_apply_ring(adsp_engine* e, void* d_out, void* stream_v) {
     }
     const int slot = (e->ring_pos + 1) % e->cfg.ring_slots;
     hipStream_t stream = (hipStream_t)stream_v;
+    if (e->pipe_depth > 1) {
+        // pipelined: the step runs on the library's stream step % depth, behind an event that marks "everything the caller has
+        // enqueued on `stream` so far" - the producer of this step's slot.  The cross-stream ordering of the ring (below) then
+        // sees alternating streams exactly as if the caller had alternated them itself.
+        hipEvent_t& ev = e->pipe_ev[e->pipe_ev_next++ % 8];
+        if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev, stream));
+        hipStream_t run = e->pipe_stream[e->step_no % e->pipe_depth];
+        HIP_TRY(hipStreamWaitEvent(run, ev, 0));
+        stream = run;
+    }
     if (e->have_last_stream && !e->multi_stream && stream != e->last_stream && (rc = ring_enter_multi_stream(e, stream))) return rc;
     adsp_engine::RingStep* rec = nullptr;
     if (e->multi_stream) {
@@ -1458,6 +1477,37 @@ int adsp_apply_ring(adsp_engine* e, void* d_out, void* stream_v) {
     if (e->lead > 0) e->lead -= 1;  // a chunk published through adsp_ring_produce_* and consumed step by step
     e->have_last_stream = true;
     e->last_stream = stream;
+    return ADSP_OK;
+}
+
+int adsp_ring_set_pipeline(adsp_engine* e, int depth) {
+    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    if (depth < 1 || depth > 2) return fail(ADSP_ERR_ARG, "pipeline depth must be 1 (steps run on the caller's stream) or 2");
+    ADSP_NOT_RESIDENT(e);
+    int rc = set_device(e);
+    if (rc) return rc;
+    if (depth > 1 && e->cfg.ring_slots < e->cfg.history_chunks + 2)
+        return fail(ADSP_ERR_ARG, "pipelined steps need ring_slots >= history_chunks + 2 (%d): with fewer the producer of step k + 1 waits for the kernel of step k",
+                    e->cfg.history_chunks + 2);
+    HIP_TRY(hipDeviceSynchronize());  // a mode switch: nothing of the ring is in flight
+    ring_forget_steps(e);
+    for (int i = 0; i < depth && depth > 1; ++i)
+        if (!e->pipe_stream[i]) HIP_TRY(hipStreamCreateWithFlags(&e->pipe_stream[i], hipStreamNonBlocking));
+    e->pipe_depth = depth;
+    return ADSP_OK;
+}
+
+int adsp_ring_join(adsp_engine* e, void* stream_v) {
+    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    int rc = set_device(e);
+    if (rc) return rc;
+    if (e->pipe_depth < 2) return ADSP_OK;  // steps already run on the caller's stream
+    for (int i = 0; i < e->pipe_depth; ++i) {
+        hipEvent_t& ev = e->pipe_ev[e->pipe_ev_next++ % 8];
+        if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev, e->pipe_stream[i]));
+        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream_v, ev, 0));
+    }
     return ADSP_OK;
 }
 
@@ -1623,7 +1673,10 @@ int adsp_live_start(adsp_engine* e, void* d_out, int out_slots, unsigned max_ste
         HIP_TRY(hipHostGetDevicePointer(&d, L.h_words, 0));
         L.h_words_dev = static_cast<unsigned*>(d);
     }
-    const size_t n_words = 4 + (size_t)ncg;
+    if ((size_t)c.n_channels * (size_t)c.chunk_size * sizeof(float) >= 0x7fffffffull)
+        return fail(ADSP_ERR_ARG, "a live session addresses a chunk batch with 32-bit byte offsets: channels x chunk must stay below 2 GiB");
+    const size_t n_pad = ((size_t)ncg + 255) & ~(size_t)255;  // the relay sweeps whole 256-word groups: padding words read 0xffffffff
+    const size_t n_words = 4 + n_pad;
     if (L.d_words_n < n_words) {
         if (L.d_words) (void)hipFree(L.d_words);
         L.d_words = nullptr;
@@ -1642,7 +1695,8 @@ int adsp_live_start(adsp_engine* e, void* d_out, int out_slots, unsigned max_ste
         e->copy_pending = false;
     }
     for (int i = 0; i < 16; ++i) L.h_words[i] = 0;
-    HIP_TRY(hipMemsetAsync(L.d_words, 0, n_words * sizeof(unsigned), stream));
+    HIP_TRY(hipMemsetAsync(L.d_words, 0, (4 + (size_t)ncg) * sizeof(unsigned), stream));
+    if (n_pad > (size_t)ncg) HIP_TRY(hipMemsetAsync(L.d_words + 4 + ncg, 0xff, (n_pad - (size_t)ncg) * sizeof(unsigned), stream));
     adsp::LiveArgs la;
     memset(&la, 0, sizeof la);
     adsp::KernelArgs& a = la.k;

@@ -199,6 +199,14 @@ class FirEngine:
             _capi.check(self._lib.adsp_ring_acquire_stream(self._h, ctypes.byref(p), _ptr(stream)))
         return p.value
 
+    def ring_set_pipeline(self, depth=2):
+        """depth 2: the library runs ring step k on its own stream k % 2 (consecutive launches overlap); the caller keeps one
+        stream for its producers and calls ring_join(stream) before that stream reads outputs.  depth 1: the default."""
+        _capi.check(self._lib.adsp_ring_set_pipeline(self._h, int(depth)))
+
+    def ring_join(self, stream=None):
+        _capi.check(self._lib.adsp_ring_join(self._h, _ptr(stream)))
+
     def ring_reset_order(self):
         """Drain the device and forget the cross-stream ordering events of the ring (before and after hipGraph capture)."""
         _capi.check(self._lib.adsp_ring_reset_order(self._h))
