@@ -535,7 +535,7 @@ def live_figures(args, fir, dev, alg_bytes, channels, chunk, steps=4096, ring=25
     eng.live_configure(step_timeout_ms=10000.0, load_mode=load_mode)
 
     def session(n_steps, how):
-        eng.live_start(out, 8, n_steps, cons)
+        eng.live_start(out, 8, n_steps, None)  # the library's own high-priority stream (a hardware queue of its own)
         time.sleep(0.002)  # resident and waiting
         t0 = time.perf_counter()
         eng.live_publish_run(n_steps, prod if how == "stream" else None)  # step by step, in a native loop (no Python per step)
@@ -557,7 +557,7 @@ def live_figures(args, fir, dev, alg_bytes, channels, chunk, steps=4096, ring=25
                                   "runs_us_per_step": [round(r[0] * 1e6, 3) for r in runs]}
     # one step into an idle session: publish -> outputs visible to the host
     n_rt = 300
-    eng.live_start(out, 8, n_rt, cons)
+    eng.live_start(out, 8, n_rt, None)
     time.sleep(0.002)
     lat = []
     for k in range(n_rt):

@@ -328,8 +328,12 @@ ADSP_API int adsp_ring_resident_status(adsp_engine* engine, int* timed_out);
  *   call), adsp_live_wait (spins on it), adsp_live_stop (ends the session once every published step is consumed, synchronises
  *   `stream`, advances the engine's ring by the steps consumed - per-step calls may follow).
  * A workgroup that waits longer than the step time-out (adsp_live_configure, default 1000 ms, 0 = for ever) gives up and the
- * session ends; adsp_live_stop then returns ADSP_ERR_STATE.  Use an explicitly created non-blocking stream for the session
- * (work on the NULL stream would wait for it).  Available for float32 engines in the stream geometry (power-of-two chunk 128 ..
+ * session ends; adsp_live_stop then returns ADSP_ERR_STATE.  stream = NULL (recommended) runs the session on a stream of the
+ * library's own, created with the HIGHEST priority: the launch never ends while its producer lives, and every command that
+ * follows it in the same HARDWARE queue waits for it - HIP maps streams onto a handful of hardware queues (on MI355X / ROCm
+ * 7.2 every sixth stream created shared the NULL stream's queue; a producer's copy then sat behind the session until the
+ * session timed out), and streams of another priority come from another pool of queues.  A caller-provided stream must be
+ * non-blocking and must not share a hardware queue with any stream that feeds the session.  Available for float32 engines in the stream geometry (power-of-two chunk 128 ..
  * 4096, fft_size = 2 x chunk_size) with lookback 5/4 N (the cut filters) or 7/4 N (the 3-band EQ); no fused effect.
  * While a session runs, anything that drains the whole device waits for it: hipDeviceSynchronize, and the set-up calls of this
  * library that contain one (adsp_set_spectrum, adsp_reset, adsp_get_state / adsp_set_state, adsp_destroy of ANY engine on the

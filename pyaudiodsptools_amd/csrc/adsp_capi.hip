@@ -371,7 +371,8 @@ struct adsp_engine {
         const adsp::LivePlanInfo* plan = nullptr;
         unsigned* d_words = nullptr;      // fine-grained device memory: [0] seq [1] done [2] stop [3] fail [4 .. 4 + ncg) progress
         size_t d_words_n = 0;
-        unsigned* h_words = nullptr;      // pinned, device-mapped host memory: [0] host_seq [1] host_done [2] host_stop
+        unsigned* h_words = nullptr;      // pinned, device-mapped host memory.  Written by the HOST: [0] host_seq [2] host_stop; written by the
+                                          // GPU, in a cache line of their own 512 bytes further on (kLiveGpuWords): [0] host_done [3..6] relay diagnostics
         unsigned* h_words_dev = nullptr;  // its device address
         unsigned published = 0;           // steps published to the session so far
         unsigned pending = 0;             // slots handed out by adsp_live_slot since the last publication
@@ -379,6 +380,8 @@ struct adsp_engine {
         int out_slots = 0;
         int ncg = 0;
         hipStream_t stream = nullptr;
+        hipStream_t own_stream = nullptr;  // highest priority: a hardware queue of its own (see adsp_live_start)
+        unsigned long long* trace = nullptr;  // ADSP_LIVE_TRACE: pinned, mapped; 64 steps x 8 stamps of workgroup 1
         int load_mode = 2;
         double timeout_ms = 1000.0;
     } live;
@@ -808,6 +811,8 @@ int adsp_destroy(adsp_engine* e) {
     if (e->pin_seq) (void)hipHostFree(e->pin_seq);
     if (e->live.h_words) (void)hipHostFree(e->live.h_words);
     if (e->live.d_words) (void)hipFree(e->live.d_words);
+    if (e->live.own_stream) (void)hipStreamDestroy(e->live.own_stream);
+    if (e->live.trace) (void)hipHostFree(e->live.trace);
     for (auto& st : e->ring_steps) {
         if (st.in) (void)hipEventDestroy(st.in);
         if (st.out) (void)hipEventDestroy(st.out);
@@ -1616,6 +1621,10 @@ int adsp_apply_ring_resident(adsp_engine* e, void* d_out, int n_steps, void* str
 
 // ---- live sessions --------------------------------------------------------------------------------------------------
 namespace {
+// The mapped control words cross PCIe in both directions without any HIP call: plain release stores / acquire loads on the host.
+inline void host_word_store(unsigned* p, unsigned v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+inline unsigned host_word_load(const unsigned* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+constexpr int kLiveGpuWords = 128;  // offset (in words) of the GPU-written part of the mapped host words
 int live_find_plan(adsp_engine* e, const adsp::LivePlanInfo** out) {
     const adsp_config& c = e->cfg;
     if (e->generic || c.sample_format != ADSP_FORMAT_F32 || c.fft_size != 2 * c.chunk_size)
@@ -1668,15 +1677,19 @@ int adsp_live_start(adsp_engine* e, void* d_out, int out_slots, unsigned max_ste
         return fail(ADSP_ERR_ARG, "a live session needs all %d workgroups resident at once, this device holds %lld of this kernel (%d per CU, one kept "
                     "as margin): use fewer channels per engine", ncg + 1, room, per_cu);
     if (!L.h_words) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&L.h_words), 16 * sizeof(unsigned), hipHostMallocMapped));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&L.h_words), 2 * kLiveGpuWords * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
         void* d = nullptr;
         HIP_TRY(hipHostGetDevicePointer(&d, L.h_words, 0));
         L.h_words_dev = static_cast<unsigned*>(d);
     }
     if ((size_t)c.n_channels * (size_t)c.chunk_size * sizeof(float) >= 0x7fffffffull)
         return fail(ADSP_ERR_ARG, "a live session addresses a chunk batch with 32-bit byte offsets: channels x chunk must stay below 2 GiB");
-    const size_t n_pad = ((size_t)ncg + 255) & ~(size_t)255;  // the relay sweeps whole 256-word groups: padding words read 0xffffffff
-    const size_t n_words = 4 + n_pad;
+    // arrival counters: slot s % A counts the workgroups that have completed step s; A = a power of two beyond the ring, so that
+    // no workgroup is ever a whole lap of the counters ahead of the slowest one
+    size_t arrival_slots = 1024;
+    while (arrival_slots <= (size_t)c.ring_slots) arrival_slots *= 2;
+    const size_t n_pad = ((size_t)ncg + 255) & ~(size_t)255;
+    const size_t n_words = 4 + n_pad + arrival_slots;
     if (L.d_words_n < n_words) {
         if (L.d_words) (void)hipFree(L.d_words);
         L.d_words = nullptr;
@@ -1690,13 +1703,24 @@ int adsp_live_start(adsp_engine* e, void* d_out, int out_slots, unsigned max_ste
         L.d_words_n = n_words;
     }
     hipStream_t stream = (hipStream_t)stream_v;
+    if (!stream) {
+        // The session's launch never ends while its producer lives, and everything behind it in the same HARDWARE queue waits
+        // for it - HIP maps streams onto a handful of hardware queues (measured: every sixth stream created shared the NULL
+        // stream's queue, the producer's copy then sat behind the session until the session timed out).  Streams of another
+        // priority come from another pool of hardware queues: the session runs on a stream of the highest priority of its own.
+        if (!L.own_stream) {
+            int least = 0, greatest = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIP_TRY(hipStreamCreateWithPriority(&L.own_stream, hipStreamNonBlocking, greatest));
+        }
+        stream = L.own_stream;
+    }
     if (e->copy_pending) {
         HIP_TRY(hipStreamWaitEvent(stream, e->ev_copy_done, 0));
         e->copy_pending = false;
     }
-    for (int i = 0; i < 16; ++i) L.h_words[i] = 0;
-    HIP_TRY(hipMemsetAsync(L.d_words, 0, (4 + (size_t)ncg) * sizeof(unsigned), stream));
-    if (n_pad > (size_t)ncg) HIP_TRY(hipMemsetAsync(L.d_words + 4 + ncg, 0xff, (n_pad - (size_t)ncg) * sizeof(unsigned), stream));
+    for (int i = 0; i < 2 * kLiveGpuWords; ++i) L.h_words[i] = 0;
+    HIP_TRY(hipMemsetAsync(L.d_words, 0, n_words * sizeof(unsigned), stream));
     adsp::LiveArgs la;
     memset(&la, 0, sizeof la);
     adsp::KernelArgs& a = la.k;
@@ -1728,11 +1752,25 @@ int adsp_live_start(adsp_engine* e, void* d_out, int out_slots, unsigned max_ste
     la.stop = L.d_words + 2;
     la.fail = L.d_words + 3;
     la.progress = L.d_words + 4;
+    la.arrivals = L.d_words + 4 + n_pad;
+    la.arrival_slots = (unsigned)arrival_slots;
     la.host_seq = L.h_words_dev;
-    la.host_done = L.h_words_dev + 1;
+    la.host_done = L.h_words_dev + kLiveGpuWords;
     la.host_stop = L.h_words_dev + 2;
     la.timeout = (unsigned long long)(L.timeout_ms * 1e5);  // 100 MHz ticks
     la.load_mode = L.load_mode;
+    la.trace = nullptr;
+    la.relay_mode = getenv("ADSP_LIVE_RELAY_OFF") ? 1 : 0;
+    if (getenv("ADSP_LIVE_TRACE")) {
+        if (!L.trace) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&L.trace), 64 * 8 * sizeof(unsigned long long), hipHostMallocMapped));
+        memset(L.trace, 0, 64 * 8 * sizeof(unsigned long long));
+        void* d = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&d, L.trace, 0));
+        la.trace = static_cast<unsigned long long*>(d);
+        la.trace_first = (unsigned)atoi(getenv("ADSP_LIVE_TRACE"));
+        la.trace_wg = getenv("ADSP_LIVE_TRACE_WG") ? atoi(getenv("ADSP_LIVE_TRACE_WG")) : 0;
+        if (la.trace_wg < 0) la.trace_wg += ncg;
+    }
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     if (e->timing) {
         if (!e->free_ev.empty()) {
@@ -1768,7 +1806,7 @@ int adsp_live_slot(adsp_engine* e, void** d_slot) {
     // the slot last carried step q - S (or, for the first lap, a history chunk the kernel loads when it starts): it is free
     // once every workgroup is past step q - (S - history)
     const int S = e->cfg.ring_slots, usable = S - e->cfg.history_chunks;
-    const unsigned done = *static_cast<volatile unsigned*>(L.h_words + 1);
+    const unsigned done = host_word_load(L.h_words + kLiveGpuWords);
     if ((long long)q - usable + 1 > (long long)done)
         return fail(ADSP_ERR_STATE, "ring full: step %u would overwrite a slot the session has not consumed yet (%u steps done, %d usable slots)", q, done, usable);
     const int slot = (int)(((long long)e->ring_pos + 1 + q) % S);
@@ -1783,7 +1821,7 @@ int adsp_live_publish_host(adsp_engine* e) {
     if (!L.active || L.pending < 1) return fail(ADSP_ERR_STATE, "adsp_live_publish without adsp_live_slot");
     L.published += L.pending;
     L.pending = 0;
-    __atomic_store_n(L.h_words, L.published, __ATOMIC_RELEASE);  // a plain store to mapped memory: no HIP call, no queue
+    host_word_store(L.h_words, L.published);  // a plain store to mapped memory: no HIP call, no command on any queue
     return ADSP_OK;
 }
 
@@ -1810,7 +1848,7 @@ int adsp_live_publish_run(adsp_engine* e, unsigned n_steps, int use_stream, void
     for (unsigned k = 0; k < n_steps; ++k) {
         const unsigned q = L.published + L.pending;
         if (q >= L.max_steps) return fail(ADSP_ERR_STATE, "the session ends after %u steps", L.max_steps);
-        if ((long long)q - usable + 1 > (long long)__atomic_load_n(L.h_words + 1, __ATOMIC_ACQUIRE)) {
+        if ((long long)q - usable + 1 > (long long)host_word_load(L.h_words + kLiveGpuWords)) {
             const int rc = adsp_live_wait(e, (unsigned)(q - usable + 1), 20000.0);
             if (rc) return rc;
         }
@@ -1826,7 +1864,7 @@ int adsp_live_publish_run(adsp_engine* e, unsigned n_steps, int use_stream, void
 int adsp_live_progress(adsp_engine* e, unsigned* steps_done) {
     if (!e || !steps_done) return fail(ADSP_ERR_ARG, "NULL argument");
     if (!e->live.h_words) return fail(ADSP_ERR_STATE, "no live session has been started");
-    *steps_done = __atomic_load_n(e->live.h_words + 1, __ATOMIC_ACQUIRE);
+    *steps_done = host_word_load(e->live.h_words + kLiveGpuWords);
     return ADSP_OK;
 }
 
@@ -1838,15 +1876,16 @@ int adsp_live_wait(adsp_engine* e, unsigned steps, double timeout_ms) {
     timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     unsigned spins = 0;
-    while (__atomic_load_n(L.h_words + 1, __ATOMIC_ACQUIRE) < steps) {
+    const unsigned* h_done = L.h_words + kLiveGpuWords;
+    while (host_word_load(h_done) < steps) {
         if ((++spins & 0x3ff) == 0) {
             timespec t1;
             clock_gettime(CLOCK_MONOTONIC, &t1);
             const double ms = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
-            if (ms > timeout_ms) return fail(ADSP_ERR_STATE, "live session: %u of %u steps done after %.1f ms", __atomic_load_n(L.h_words + 1, __ATOMIC_ACQUIRE), steps, ms);
-            if (hipStreamQuery(L.stream) == hipSuccess && __atomic_load_n(L.h_words + 1, __ATOMIC_ACQUIRE) < steps)
+            if (ms > timeout_ms) return fail(ADSP_ERR_STATE, "live session: %u of %u steps done after %.1f ms", host_word_load(h_done), steps, ms);
+            if (hipStreamQuery(L.stream) == hipSuccess && host_word_load(h_done) < steps)
                 return fail(ADSP_ERR_STATE, "the live session has ended (time-out of a workgroup, or stopped) with %u of %u steps done",
-                            __atomic_load_n(L.h_words + 1, __ATOMIC_ACQUIRE), steps);
+                            host_word_load(h_done), steps);
             (void)hipGetLastError();
         }
     }
@@ -1867,13 +1906,39 @@ int adsp_live_stop(adsp_engine* e, unsigned* steps_consumed) {
     if (!L.active) return fail(ADSP_ERR_STATE, "no live session (adsp_live_start)");
     int rc = set_device(e);
     if (rc) return rc;
-    __atomic_store_n(L.h_words + 2, 1u, __ATOMIC_RELEASE);
+    host_word_store(L.h_words + 2, 1u);
     HIP_TRY(hipStreamSynchronize(L.stream));
     std::vector<unsigned> w(4 + (size_t)L.ncg);
     HIP_TRY(hipMemcpy(w.data(), L.d_words, w.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
     unsigned done = 0xffffffffu;
     for (int i = 0; i < L.ncg; ++i) done = w[4 + i] < done ? w[4 + i] : done;
     const bool timed_out = w[3] != 0;
+    if (getenv("ADSP_DEBUG")) {
+        fprintf(stderr, "libadsp live_stop: seq %u done %u stop %u fail %u | host_seq %u host_done %u host_stop %u | published %u | progress:", w[0], w[1], w[2],
+                w[3], L.h_words[0], L.h_words[kLiveGpuWords], L.h_words[2], L.published);
+        const unsigned* g = L.h_words + kLiveGpuWords;
+        fprintf(stderr, " h_words %p dev %p d_words %p |", (void*)L.h_words, (void*)L.h_words_dev, (void*)L.d_words);
+        fprintf(stderr, " relay: %u iterations, last host_seq %u, exit reason %u |", g[3], g[4], g[6]);
+        for (int i = 0; i < L.ncg && i < 64; ++i) fprintf(stderr, " %u", w[4 + i]);
+        fprintf(stderr, "\n");
+    }
+    if (L.trace && getenv("ADSP_LIVE_TRACE")) {
+        // average shader cycles between the stamps of workgroup 1 over steps 8 .. 63: top -> chunk requested/waited -> chunk arrived ->
+        // window built (+ fetch-ahead issued) -> transform done -> stores issued -> next top
+        double seg[6] = {0, 0, 0, 0, 0, 0};
+        int n = 0;
+        for (int st = 1; st < 63; ++st) {
+            const unsigned long long* t = L.trace + st * 8;
+            if (!t[0] || !L.trace[(st + 1) * 8]) continue;
+            for (int k = 0; k < 5; ++k) seg[k] += (double)(t[k + 1] - t[k]);
+            seg[5] += (double)(L.trace[(st + 1) * 8] - t[5]);
+            ++n;
+        }
+        if (n)
+            fprintf(stderr, "libadsp live trace (workgroup 1, %d steps, shader cycles): wait+request %.0f | chunk arrives %.0f | window %.0f | transform %.0f | "
+                    "confirm+stores %.0f | tail %.0f | step %.0f\n", n, seg[0] / n, seg[1] / n, seg[2] / n, seg[3] / n, seg[4] / n, seg[5] / n,
+                    (seg[0] + seg[1] + seg[2] + seg[3] + seg[4] + seg[5]) / n);
+    }
     L.active = false;
     // the ring moves on by the steps EVERY channel group consumed (after a time-out some may be further: adsp_reset then)
     const int S = e->cfg.ring_slots;

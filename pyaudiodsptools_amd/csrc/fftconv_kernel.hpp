@@ -122,7 +122,10 @@ struct LiveArgs {
     unsigned* seq;                 // device word (fine-grained): steps published so far; device-side producers bump it themselves
     const volatile unsigned* host_seq;  // host-mapped word a HOST producer bumps with a plain store (no HIP call); the relay workgroup
                                    // forwards it into *seq
-    unsigned* progress;            // [ncg] device words: steps this workgroup has completed (outputs written through to memory)
+    unsigned* progress;            // [ncg] device words: steps this workgroup had completed when it left (adsp_live_stop reads them)
+    unsigned* arrivals;            // [arrival_slots] device words: slot s % arrival_slots counts the workgroups that have completed step s
+                                   // (one returnless atomic per workgroup and step; after lap L of the slots it reads ncg * (L + 1))
+    unsigned arrival_slots;        // a power of two > ring_slots: no workgroup is ever that many steps ahead of the slowest one
     unsigned* done;                // device word: min over progress[] (maintained by the relay workgroup)
     volatile unsigned* host_done;  // the same, host-mapped: the host reads it without a HIP call
     const volatile unsigned* host_stop;  // host-mapped: non-zero = end the session once every published step is consumed
@@ -130,6 +133,10 @@ struct LiveArgs {
     unsigned* fail;                // set by a workgroup that gave up waiting (time-out)
     unsigned long long timeout;    // ticks of the 100 MHz clock a workgroup waits for ONE step (0 = for ever)
     int load_mode;                 // 0 plain, 1 non-temporal, 2 system-scope (sc0 sc1) loads of the new chunk (tuning; default 2)
+    unsigned long long* trace;     // tuning (ADSP_LIVE_TRACE=<first step>): workgroup trace_wg stamps s_memtime at six points of 64 steps
+    unsigned trace_first;
+    int trace_wg;
+    int relay_mode;                // tuning: 1 = the relay leaves at once (publications must then come from the device side)
 };
 
 #define ADSP_F64 0

@@ -11,18 +11,24 @@ __global__ void live_publish_kernel(unsigned* seq, unsigned value) {
     __hip_atomic_fetch_max(seq, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// exchange buffers + the pass twiddles, which a session keeps in LDS
+template <class PL, int CPB>
+constexpr int live_lds_bytes() {
+    return lds_bytes<PL, CPB>() + PL::tw_total * (int)sizeof(real4);
+}
+
 template <class PL, int CPB, int LQ>
 hipError_t live_launch(const LiveArgs& a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((fftconv_live_kernel<PL, CPB, 8, LQ>), dim3(grid), dim3(PL::T * CPB), (lds_bytes<PL, CPB>()), s, a);
+    hipLaunchKernelGGL((fftconv_live_kernel<PL, CPB, 8, LQ>), dim3(grid), dim3(PL::T * CPB), (live_lds_bytes<PL, CPB>()), s, a);
     return hipGetLastError();
 }
 
 template <class PL, int CPB, int LQ>
 hipError_t live_capacity(int* blocks_per_cu) {
     const void* fn = reinterpret_cast<const void*>(&fftconv_live_kernel<PL, CPB, 8, LQ>);
-    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<PL, CPB>());
+    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, live_lds_bytes<PL, CPB>());
     if (err != hipSuccess) return err;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, PL::T * CPB, lds_bytes<PL, CPB>());
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, PL::T * CPB, live_lds_bytes<PL, CPB>());
 }
 
 template <class PL, int CPB, int LQ>
