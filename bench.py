@@ -214,14 +214,19 @@ class Runner:
             if pipelined:
                 eng.ring_set_pipeline(2)
 
+            # pipelined: the caller's ONE stream is an explicitly created one (measured: with the legacy NULL stream in that role and
+            # a ring of history + 3 or more slots a step took 67.9 us instead of 49.3 - profiles/r4_stream_pipeline.txt)
+            self.user_stream = torch.cuda.Stream(device=dev) if pipelined else None
+            uptr = self.user_stream.cuda_stream if pipelined else sptr
+
             def run(k_steps, sp=None):
                 if pipelined and sp is None:
-                    # the library alternates its own two streams; this stream carries the (absent) producers, whose slot is
+                    # the library alternates its own two streams; the caller's stream carries the (absent) producers, whose slot is
                     # acquired on it so that the ring ordering is part of what is timed, and joins the steps at the end
                     for i in range(k_steps):
-                        eng.ring_acquire(sptr)
-                        eng.apply_ring(self.outs[i % 4], sptr)
-                    eng.ring_join(sptr)
+                        eng.ring_acquire(uptr)
+                        eng.apply_ring(self.outs[i % 4], uptr)
+                    eng.ring_join(uptr)
                 elif sp is not None or len(sps) == 1:
                     for i in range(k_steps):
                         eng.apply_ring(self.outs[i % 4], sp if sp is not None else sptr)

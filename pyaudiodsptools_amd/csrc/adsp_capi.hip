@@ -382,6 +382,9 @@ struct adsp_engine {
         hipStream_t stream = nullptr;
         hipStream_t own_stream = nullptr;  // highest priority: a hardware queue of its own (see adsp_live_start)
         unsigned long long* trace = nullptr;  // ADSP_LIVE_TRACE: pinned, mapped; 64 steps x 8 stamps of workgroup 1
+        // tables of a session plan that is not the engine's own (config 3 runs on 8 points per thread): rebuilt at every start
+        void *own_tw = nullptr, *own_pair = nullptr, *own_pair0 = nullptr;
+        size_t own_tw_bytes = 0, own_pair_bytes = 0, own_pair0_bytes = 0;
         int load_mode = 2;
         double timeout_ms = 1000.0;
     } live;
@@ -405,13 +408,15 @@ int set_device(const adsp_engine* e) {
 // async = false: blocking copies (the caller has drained the device: nothing is reading the tables).
 // async = true : the tables are staged in pinned memory and copied ON `stream`, i.e. after every launch already queued
 //                there and before every later one - no device-wide synchronisation, the filter changes between two steps.
+// The spectrum-stage tables of one plan: `tab` (per-thread rows) and `tab0` (the self-paired butterflies), from the spectrum H of
+// M + 1 bins.  Shared by the engine's own plan and by the plan a live session runs on (adsp_live_start).
 template <class R, class HT>
-int upload_pairs_t(adsp_engine* e, const HT* H, hipStream_t stream, bool async) {
+void build_pair_tables(const PlanInfo& pl, int M, const HT* H, bool real_spec, std::vector<typename Vec<R>::T4>& tab,
+                       std::vector<typename Vec<R>::T2>& tab0) {
     using V = Vec<R>;
     using T2 = typename V::T2;
     using T4 = typename V::T4;
-    const PlanInfo& pl = *e->plan;
-    const int M = e->M, T = pl.T;
+    const int T = pl.T;
     const int RR = pl.rad[pl.NP - 1];        // radix of the paired passes: P for XL plans, P/2, P/4 .. otherwise
     const int D = M / RR;                     // bin spacing between a butterfly's outputs
     const int PU = pl.XL ? 1 : pl.P / RR / 2; // pairs of butterflies per thread (in-register plans: (u*T + t, its mirror))
@@ -422,20 +427,8 @@ int upload_pairs_t(adsp_engine* e, const HT* H, hipStream_t stream, bool async) 
         return (t & 32) ? (t == 32 ? T / 2 : T - lo) : lo;
     };
     auto self_paired = [&](int t, int u) { return (t == 0 && u == 0) || (pl.XL && t == 32); };  // served by tab0
-    // A real spectrum (zero-phase kernel) makes c1, c4 real and c2 imaginary: 3 floats per pair instead of 6.
-    bool real_spec = true;
-    for (int k = 0; k <= M && real_spec; ++k) real_spec = H[2 * k + 1] == (HT)0;
-    if (getenv("ADSP_FORCE_COMPLEX")) real_spec = false;  // tuning: A/B the two spectrum stages on the same filter
-    e->real_spec = real_spec;
-    if constexpr (std::is_same<HT, float>::value) {
-        if (e->host_spec.data() != H) e->host_spec.assign(H, H + 2 * (size_t)(M + 1));
-        e->host_spec64.clear();
-    } else {
-        e->host_spec.clear();
-        if (e->host_spec64.data() != H) e->host_spec64.assign(H, H + 2 * (size_t)(M + 1));
-    }
     // float4 layout [u][h][3][T]: (wc,g1) of pair 2h, (g2 of 2h, wc of 2h+1), (g1,g2) of 2h+1
-    std::vector<T4> tab((size_t)PU * (npairs / 2) * 3 * T, V::m4(0, 0, 0, 0));
+    tab.assign((size_t)PU * (npairs / 2) * 3 * T, V::m4(0, 0, 0, 0));
     if (real_spec) {
         // [u][g][3][T] float4 = (c1.re, c4.re, c2.im) of pairs 4g .. 4g+3
         std::vector<double> flat(12);
@@ -465,7 +458,7 @@ int upload_pairs_t(adsp_engine* e, const HT* H, hipStream_t stream, bool async) 
                 tab[(row + 1) * T + tid] = V::m4(a.g2.x, a.g2.y, b.wc.x, b.wc.y);
                 tab[(row + 2) * T + tid] = V::m4(b.g1.x, b.g1.y, b.g2.x, b.g2.y);
             }
-    std::vector<T2> tab0((size_t)(RR + 1) * 3);
+    tab0.assign((size_t)(RR + 1) * 3, V::m2(0, 0));
     auto put0 = [&](int idx, int k) {
         const PairEntry<R> pe = pair_entry<R>(H, M, k);
         tab0[idx * 3 + 0] = pe.wc;
@@ -476,6 +469,29 @@ int upload_pairs_t(adsp_engine* e, const HT* H, hipStream_t stream, bool async) 
     put0(1, M / 2);
     for (int r = 1; r < RR / 2; ++r) put0(2 + (r - 1), D * r);
     for (int r = 0; r < RR / 2; ++r) put0(2 + (RR / 2 - 1) + r, D / 2 + D * r);
+}
+
+template <class R, class HT>
+int upload_pairs_t(adsp_engine* e, const HT* H, hipStream_t stream, bool async) {
+    using V = Vec<R>;
+    using T2 = typename V::T2;
+    using T4 = typename V::T4;
+    const int M = e->M;
+    // A real spectrum (zero-phase kernel) makes c1, c4 real and c2 imaginary: 3 floats per pair instead of 6.
+    bool real_spec = true;
+    for (int k = 0; k <= M && real_spec; ++k) real_spec = H[2 * k + 1] == (HT)0;
+    if (getenv("ADSP_FORCE_COMPLEX")) real_spec = false;  // tuning: A/B the two spectrum stages on the same filter
+    e->real_spec = real_spec;
+    if constexpr (std::is_same<HT, float>::value) {
+        if (e->host_spec.data() != H) e->host_spec.assign(H, H + 2 * (size_t)(M + 1));
+        e->host_spec64.clear();
+    } else {
+        e->host_spec.clear();
+        if (e->host_spec64.data() != H) e->host_spec64.assign(H, H + 2 * (size_t)(M + 1));
+    }
+    std::vector<T4> tab;
+    std::vector<T2> tab0;
+    build_pair_tables<R, HT>(*e->plan, M, H, real_spec, tab, tab0);
     const size_t b1 = tab.size() * sizeof(T4), b0 = tab0.size() * sizeof(T2);
     if (async) {
         if (e->pin_tab_bytes < b1 + b0) {  // first use (the table size of an engine never changes afterwards)
@@ -813,6 +829,8 @@ int adsp_destroy(adsp_engine* e) {
     if (e->live.d_words) (void)hipFree(e->live.d_words);
     if (e->live.own_stream) (void)hipStreamDestroy(e->live.own_stream);
     if (e->live.trace) (void)hipHostFree(e->live.trace);
+    for (void* p : {e->live.own_tw, e->live.own_pair, e->live.own_pair0})
+        if (p) (void)hipFree(p);
     for (auto& st : e->ring_steps) {
         if (st.in) (void)hipEventDestroy(st.in);
         if (st.out) (void)hipEventDestroy(st.out);
@@ -1633,8 +1651,9 @@ int live_find_plan(adsp_engine* e, const adsp::LivePlanInfo** out) {
     const int lq = c.lookback / (c.chunk_size / 4);
     int n = 0;
     const adsp::LivePlanInfo* tab = adsp::live_plans(&n);
+    const bool skip8 = getenv("ADSP_LIVE_PLAN16") != nullptr;  // tuning: the 16-points-per-thread plan where the 8-point one would be chosen
     for (int i = 0; i < n; ++i)
-        if (tab[i].M == e->M && tab[i].LQ == lq) {
+        if (tab[i].M == e->M && tab[i].LQ == lq && (c.out_offset / (2 * tab[i].T)) % 2 == 0 && !(skip8 && tab[i].P <= 8)) {  // (the kept rows start on a register pair)
             *out = &tab[i];
             return ADSP_OK;
         }
@@ -1673,9 +1692,9 @@ int adsp_live_start(adsp_engine* e, void* d_out, int out_slots, unsigned max_ste
     HIP_TRY(lp->capacity(&per_cu));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device_id));
     const long long room = (long long)(per_cu > 1 ? per_cu - 1 : per_cu) * cus;
-    if ((long long)ncg + 1 > room)
+    if ((long long)ncg + 2 > room)
         return fail(ADSP_ERR_ARG, "a live session needs all %d workgroups resident at once, this device holds %lld of this kernel (%d per CU, one kept "
-                    "as margin): use fewer channels per engine", ncg + 1, room, per_cu);
+                    "as margin): use fewer channels per engine", ncg + 2, room, per_cu);
     if (!L.h_words) {
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&L.h_words), 2 * kLiveGpuWords * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
         void* d = nullptr;
@@ -1689,7 +1708,7 @@ int adsp_live_start(adsp_engine* e, void* d_out, int out_slots, unsigned max_ste
     size_t arrival_slots = 1024;
     while (arrival_slots <= (size_t)c.ring_slots) arrival_slots *= 2;
     const size_t n_pad = ((size_t)ncg + 255) & ~(size_t)255;
-    const size_t n_words = 4 + n_pad + arrival_slots;
+    const size_t n_words = 4 + n_pad + arrival_slots * 256;  // sixteen 64-byte shards per slot
     if (L.d_words_n < n_words) {
         if (L.d_words) (void)hipFree(L.d_words);
         L.d_words = nullptr;
@@ -1743,6 +1762,43 @@ int adsp_live_start(adsp_engine* e, void* d_out, int out_slots, unsigned max_ste
     a.inv_n = 1.0f / (float)c.chunk_size;
     a.real_spec = e->real_spec ? 1 : 0;
     a.win_pairs = e->plan->P / 2;
+    {
+        const PlanInfo& ep = *e->plan;
+        bool same = ep.P == lp->P && ep.NP == lp->NP && ep.XL == lp->XL && ep.T == lp->T;
+        for (int i = 0; i < 4 && same; ++i) same = ep.rad[i] == lp->rad[i];
+        if (!same) {
+            // the session's plan is not the engine's: its own twiddle and spectrum-stage tables, from the spectrum the engine keeps
+            PlanInfo sp = ep;
+            sp.P = lp->P, sp.T = lp->T, sp.NP = lp->NP, sp.XL = lp->XL, sp.CPB = lp->CPB, sp.tw_total = lp->tw_total;
+            for (int i = 0; i < 4; ++i) sp.rad[i] = lp->rad[i];
+            std::vector<float4> tw, tab;
+            std::vector<float2> tab0;
+            build_twiddles<float>(sp, tw);
+            if ((int)tw.size() != lp->tw_total) return fail(ADSP_ERR_STATE, "internal: live plan twiddle count %zu != %d", tw.size(), lp->tw_total);
+            if (!e->host_spec.empty()) build_pair_tables<float, float>(sp, e->M, e->host_spec.data(), e->real_spec, tab, tab0);
+            else if (!e->host_spec64.empty()) build_pair_tables<float, double>(sp, e->M, e->host_spec64.data(), e->real_spec, tab, tab0);
+            else return fail(ADSP_ERR_STATE, "internal: the engine kept no copy of its spectrum");
+            auto put = [&](void*& d, size_t& have, const void* src, size_t bytes) -> hipError_t {
+                if (have < bytes) {
+                    if (d) (void)hipFree(d);
+                    d = nullptr;
+                    have = 0;
+                    hipError_t err = hipMalloc(&d, bytes);
+                    if (err != hipSuccess) return err;
+                    have = bytes;
+                }
+                return hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, stream);
+            };
+            tw.push_back(make_float4(0.f, 0.f, 0.f, 0.f));  // (one entry of padding, like the engine's own table)
+            HIP_TRY(put(L.own_tw, L.own_tw_bytes, tw.data(), tw.size() * sizeof(float4)));
+            HIP_TRY(put(L.own_pair, L.own_pair_bytes, tab.data(), tab.size() * sizeof(float4)));
+            HIP_TRY(put(L.own_pair0, L.own_pair0_bytes, tab0.data(), tab0.size() * sizeof(float2)));
+            HIP_TRY(hipStreamSynchronize(stream));  // (the host vectors go out of scope)
+            a.tw = L.own_tw;
+            a.pair = L.own_pair;
+            a.pair0 = L.own_pair0;
+        }
+    }
     la.out = d_out;
     la.out_slots = out_slots;
     la.first_pub = 0;
@@ -1782,7 +1838,7 @@ int adsp_live_start(adsp_engine* e, void* d_out, int out_slots, unsigned max_ste
         }
         HIP_TRY(hipEventRecord(ev.first, stream));
     }
-    HIP_TRY(lp->launch(la, ncg + 1, stream));
+    HIP_TRY(lp->launch(la, ncg + 2, stream));  // the workers, then the two relay blocks
     if (e->timing) {
         HIP_TRY(hipEventRecord(ev.second, stream));
         e->timed.push_back(ev);

@@ -123,8 +123,10 @@ struct LiveArgs {
     const volatile unsigned* host_seq;  // host-mapped word a HOST producer bumps with a plain store (no HIP call); the relay workgroup
                                    // forwards it into *seq
     unsigned* progress;            // [ncg] device words: steps this workgroup had completed when it left (adsp_live_stop reads them)
-    unsigned* arrivals;            // [arrival_slots] device words: slot s % arrival_slots counts the workgroups that have completed step s
-                                   // (one returnless atomic per workgroup and step; after lap L of the slots it reads ncg * (L + 1))
+    unsigned* arrivals;            // [arrival_slots][16 shards][16 words]: shard cg % 16 of slot s % arrival_slots counts the workgroups of that
+                                   // residue that have completed step s - one returnless atomic per workgroup and step, each shard a 64-byte
+                                   // line of its own (atomics on ONE word serialise: ~90 per us, and a step of config 3 has 4096 of them);
+                                   // after lap L of the slots a shard reads (workgroups of its residue) * (L + 1)
     unsigned arrival_slots;        // a power of two > ring_slots: no workgroup is ever that many steps ahead of the slowest one
     unsigned* done;                // device word: min over progress[] (maintained by the relay workgroup)
     volatile unsigned* host_done;  // the same, host-mapped: the host reads it without a HIP call

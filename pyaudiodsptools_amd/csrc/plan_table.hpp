@@ -25,6 +25,8 @@ struct PlanInfo {
 // one persistent kernel of the live sessions: M = N complex points (F = 2N), lookback LQ quarter chunks
 struct LivePlanInfo {
     int M, CPB, LQ, T;
+    int P, NP, XL, rad[4], tw_total;  // the plan itself: a session whose plan is not the engine's builds its own tables from this
+    int tw_in_lds;                    // the kernel keeps the pass twiddles in LDS
     hipError_t (*launch)(const LiveArgs&, int grid, hipStream_t);
     hipError_t (*capacity)(int* blocks_per_cu);  // sets the kernel's LDS attribute, asks the occupancy API
 };
