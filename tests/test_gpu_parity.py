@@ -365,9 +365,11 @@ def test_spectrum_update_keeps_history(adsp, live):
 
 def test_errors_cross_the_abi_as_exceptions(adsp):
     from pyaudiodsptools_amd import _capi
-    adsp.config.initialize(44100, 3002)
+    adsp.config.initialize(44100, 3)
     with pytest.raises(ValueError):
-        adsp.CreateLowCutFilter(800)  # chunk sizes must be multiples of 4
+        adsp.CreateLowCutFilter(800)  # N // 2 - 1 = 0 taps: no filter (round 4: every chunk size from 4 up is accepted, 3002 included)
+    adsp.config.initialize(44100, 3002)
+    assert adsp.CreateLowCutFilter(800).apply(np.zeros(3002, np.float32)).shape == (3002,)
     adsp.config.initialize(44100, 512)
     dev = adsp.CreateLowCutFilter(800, channels=2)
     with pytest.raises(ValueError):
@@ -642,7 +644,7 @@ def test_raw_c_abi_error_paths(adsp):
 
     # lookback 704 / out_offset 192 are multiples of 2*threads_per_transform (64) but not of N/4 (128): the specialised
     # kernels resolve window and kept-slice phases in quarter chunks, so the ABI refuses them
-    for bad in (dict(chunk_size=502), dict(fft_size=500), dict(fft_size=65536), dict(n_channels=0), dict(history_chunks=0), dict(lookback=641),
+    for bad in (dict(chunk_size=3), dict(chunk_size=502, sample_format=1), dict(fft_size=500), dict(fft_size=65536), dict(n_channels=0), dict(history_chunks=0), dict(lookback=641),
                 dict(lookback=4096), dict(out_offset=1000), dict(out_offset=768, lookback=640), dict(ring_slots=2),
                 dict(lookback=704), dict(out_offset=192),
                 dict(device_id=99), dict(sample_format=7)):
