@@ -587,6 +587,17 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
     a.lookback = c.lookback;
     a.j0 = c.out_offset;
     a.ncg = (c.n_channels + pl.CPB - 1) / pl.CPB;
+    // non-temporal loads for the part of a window no other block reads; the head and the tail (F - V samples each, whole register pairs)
+    // stay in L2 for the neighbouring blocks of the channel
+    a.nt_lo = 0;
+    a.nt_hi = pl.P / 2;
+    if (pl.P >= 64 && !e->generic && n_steps > 1 && !(getenv("ADSP_NT_HYBRID") && atoi(getenv("ADSP_NT_HYBRID")) == 0)) {  // (ADSP_NT_HYBRID=0: tuning A/B)
+        const int seg = 4 * pl.T, overlap = (c.fft_size - a.V + seg - 1) / seg;
+        if (2 * overlap < pl.P / 2) {
+            a.nt_lo = overlap;
+            a.nt_hi = pl.P / 2 - overlap;
+        }
+    }
     const long long grid = (long long)((a.ncg + 7) / 8) * 8 * (resident ? (a.nblk + a.step_tile - 1) / a.step_tile * a.step_tile : a.nblk);  // resident: whole step tiles
     if (grid > 0x7fffffffLL) return fail(ADSP_ERR_ARG, "launch too large (%lld workgroups)", grid);
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};

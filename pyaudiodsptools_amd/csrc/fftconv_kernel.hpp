@@ -97,6 +97,9 @@ struct KernelArgs {
     int win_pairs;         // register PAIRS of the window that are loaded (P/2 = all); the rest is taken as zero: window
                            // positions >= out_offset + V + (kernel taps at negative circular indices) only feed discarded
                            // outputs - a single-step launch of a zero-phase cut filter needs 1.5 N of its 2 N window
+    int nt_lo, nt_hi;      // multi-step launches: register pairs nt_lo <= u < nt_hi of the window are loaded non-temporally, the others - the
+                           // head and the tail, which the neighbouring blocks of the channel read as well - with plain loads that leave
+                           // the lines in L2 for them (0, P/2: everything non-temporal)
     int accumulate;        // 1: add the kept samples to what `out` holds (partitioned FIRs, mixing); 2: and clip the sum
                            // to [-1, 1] (MixSignals).  Plain kernels: generic geometry + mode 1 only; EPI kernels: all.
     // resident ring launches (adsp_apply_ring_resident): the new chunks are ring slots too (`in` is unused) and block b may

@@ -6,7 +6,7 @@ root="$(cd "$(dirname "$0")/.." && pwd)"
 tmp=$(mktemp -d)
 mkdir -p "$root/abl"
 cd "$root/pyaudiodsptools_amd/csrc"
-for f in adsp_capi adsp_rccl adsp_delay adsp_scan adsp_exact plans_f32 plans_s16 plans_s16_f64 plans_f32_epi plans_var; do
+for f in adsp_capi adsp_rccl adsp_delay adsp_scan adsp_exact plans_f32 plans_s16 plans_s16_f64 plans_f32_epi plans_var plans_live; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fvisibility=hidden -Wno-unused-function -fno-slp-vectorize "$@" -c -o $tmp/$f.o $f.hip &
 done
 wait
