@@ -2,12 +2,13 @@
 """Run config 3 as live sessions (adsp_live_*) under rocprofv3 --kernel-trace: the persistent launch shows up as ONE dispatch of
 adsp::fftconv_live_kernel per session, whose duration / steps is the per-step time the bench line quotes (tools/sessions/r4_session14.sh)."""
 import json
+import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from pyaudiodsptools_amd import FirEngine, design  # noqa: E402
 
