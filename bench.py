@@ -756,6 +756,44 @@ def main():
                                           "of": "adsp_get_spectrum of every rank's engine"}
         if os.environ.get("ADSP_BENCH_REEXEC") == "1":
             dist_info["launcher"] = "bench.py re-executed itself under torch.distributed.run (plain `python3 bench.py --gpus N`)"
+    # The same collective through the C ABI (adsp_bcast_spectrum_rank: RCCL opened by libadsp, ncclCommInitRank, the id handed over
+    # through a file) as a cross-check on real multi-GPU hardware: a small engine per rank, every rank starts from zeros except
+    # rank 0, checksums gathered.  Fenced by a thread + time-out - it may not cost the driver its line.
+    if barrier is not None and backend == "nccl" and os.environ.get("ADSP_BENCH_ABI_CHECK", "1") == "1":
+        import hashlib
+        import threading
+        abi = {"status": "not run"}
+
+        def abi_work():
+            try:
+                from pyaudiodsptools_amd import FirEngine
+                from pyaudiodsptools_amd.engine import rccl_unique_id
+                eng = FirEngine(fir, channels=8, device=local_rank, fft_mult=args.fft_mult, sample_format=args.io,
+                                optimize_for="stream" if args.mode == "stream" else "batch")  # (the main engine's geometry and spectrum)
+                if rank != 0:
+                    eng.upload_spectrum(np.zeros_like(eng.spectrum))  # only rank 0 carries the filter
+                uid = adist.exchange_unique_id(rank, world, rccl_unique_id)
+                eng.bcast_rank(uid, rank, world, 0)
+                abi["sum"] = int.from_bytes(hashlib.blake2b(np.ascontiguousarray(eng.get_spectrum()).tobytes(), digest_size=8).digest(), "little", signed=True)
+                abi["status"] = "ok"
+                eng.close()
+            except BaseException as exc:
+                abi["status"] = f"error: {type(exc).__name__}: {exc}"[:200]
+        try:
+            th = threading.Thread(target=abi_work, daemon=True)
+            th.start()
+            th.join(90.0)
+            if th.is_alive():
+                abi["status"] = "time-out after 90 s"
+        except BaseException as exc:  # (every rank must reach the all_gather below whatever happened here)
+            abi["status"] = f"error: {type(exc).__name__}: {exc}"[:200]
+        tl = torch.tensor([1 if abi["status"] == "ok" else 0, abi.get("sum", 0) if abi["status"] == "ok" else 0], device=red_dev, dtype=torch.int64)
+        gathered = [torch.zeros_like(tl) for _ in range(tdist.get_world_size())]
+        tdist.all_gather(gathered, tl)
+        oks, sums2 = [int(g[0]) for g in gathered], [int(g[1]) for g in gathered]
+        dist_info["abi_carrier_check"] = {"carrier": "adsp_bcast_spectrum_rank (ncclCommInitRank inside libadsp, id through a file)", "ranks_ok": sum(oks),
+                                          "equal_on_all_ranks": all(oks) and len(set(sums2)) == 1, "matches_torch_carrier": all(oks) and sums2[0] == sums[0],
+                                          "rank0_status": abi["status"]}
     med, runs_block = summarize_runs(runs, main_run.samples_per_step * world, steps)
     wall, kern_ms, launches, _ = runs[med]
     if parity is not None:
@@ -936,6 +974,8 @@ def main():
     if barrier is not None:
         tdist.barrier()
         tdist.destroy_process_group()
+    if dist_info.get("abi_carrier_check", {}).get("rank0_status", "").startswith("time-out"):
+        os._exit(0)  # (a collective that never returned holds a thread: do not wait for it at interpreter exit)
 
 
 if __name__ == "__main__":

@@ -197,3 +197,28 @@ def test_sharded_bank_abi_carrier_host_logic(monkeypatch):
     assert np.array_equal(bank.spectrum, np.arange(4, dtype=np.float32))
     with pytest.raises(ValueError):
         dist.ShardedFirBank(fir, 10, engine_factory=_FakeAbiEngine, carrier="mpi")
+
+
+def test_local_bank_float64_engines_keep_their_filter_through_the_broadcast():
+    """sample_format='s16_f64' with the banks.  LocalFirBank hands the engines to broadcast_filter untouched (the float64
+    spectrum travels as float64 inside adsp_bcast_spectrum: no float32 re-upload), ShardedFirBank checks cross-rank agreement on
+    the float32 image and leaves the float64 tables alone."""
+    from pyaudiodsptools_amd import FirStream, design, dist
+    seen = []
+
+    class Eng:
+        def __init__(self, fir, channels=1, device=0, ring_slots=0, **kw):
+            self.kw, self.channels, self.uploads = kw, channels, 0
+
+        def upload_spectrum(self, *a, **k):
+            self.uploads += 1
+
+        def upload_spectrum_device(self, *a, **k):
+            self.uploads += 1
+
+    fir = FirStream(design.lowcut_kernel(300, 44100, 512), 512)
+    bank = dist.LocalFirBank(fir, 10, devices=[0, 1], sample_format="s16_f64", engine_factory=Eng, broadcast=lambda engines, root: seen.append((len(engines), root)))
+    assert seen == [(2, 0)] and all(e.kw == {"sample_format": "s16_f64"} and e.uploads == 0 for e in bank.engines)
+    bank.close()
+    sb = dist.ShardedFirBank(fir, 4, engine_factory=Eng, sample_format="s16_f64", carrier="torch")
+    assert sb.engine.uploads == 0 and sb.engine.kw == {"sample_format": "s16_f64"}

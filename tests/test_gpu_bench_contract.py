@@ -59,3 +59,6 @@ def test_other_workloads_and_the_rccl_path_print_the_same_line():
     d, lines = run_bench("--steps", "2", "--warmup", "1", "--no-stream-extra", "--no-latency", "--no-cpu-baseline",
                          env={"ADSP_BENCH_FORCE_PG": "1", "MASTER_PORT": "29541"})  # init_process_group("nccl") at world size 1
     assert d["n_gpus"] == 1 and d["value"] > 0 and lines[-1].lstrip().startswith("{")
+    # ... and the same collective once more through the C ABI (adsp_bcast_spectrum_rank), cross-checked against the torch carrier
+    chk = d["abi_carrier_check"]
+    assert chk["ranks_ok"] == 1 and chk["equal_on_all_ranks"] and chk["matches_torch_carrier"], chk
