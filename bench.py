@@ -7,26 +7,31 @@ Workload (BASELINE.json configs[1]): CreateLowCutFilter(800) @ 44.1 kHz on 4096 
 4096-sample chunks per GPU, float32, synthetic uniform(-1,1) input already resident in HBM.
 
 A "step" is ONE PASS OF THE HOT PATH OVER ONE RESIDENT BATCH.  Default mode "batch": a batch is
-[chunks_per_step = 96, channels, chunk] float32 (6.4 GB in + 6.4 GB out at the default shape: many chunks of every
-channel batched as one grid, each 2N transform keeping 1.5 N samples) and a step is one adsp_apply_device launch over
-it; K steps = K launches over distinct resident batches.  (Round 1 counted single chunks as steps; the driver's
-`--steps 20` then timed a 0.8 ms region made of one ragged launch.  A step that is a whole batch makes the figure
-independent of K: 16 steps by default, 20 when the driver says so.)  `--mode stream` runs one launch per step over a
-[channels, chunk] batch through the zero-copy ring (adsp_apply_ring), the real-time call pattern; its figure is also
-measured (after the timed region) and reported under "stream" in the same line: launch by launch, replayed as a
-hipGraph, and with consecutive steps on two HIP streams in turn ("two_streams": a step depends on the ring, not on the
-previous step's kernel).  History is carried by the engine exactly as between reference apply() calls; every output sample of every
-step is produced inside the timed region.  Before the W warmup steps the same workload runs untimed for --prewarm-ms
-(default 300 ms): an idle MI355X needs tens of milliseconds of sustained load before its shader clock has ramped up.
+[chunks_per_step = 98, channels, chunk] float32 (6.6 GB in + 6.6 GB out at the default shape: many chunks of every
+channel batched as one grid, each 4N transform keeping 3.5 N samples) and a step is one adsp_apply_device launch over
+it.  W untimed warm-up steps, then FIVE timed regions (--runs) of EXACTLY K steps each, every one bracketed by a barrier +
+synchronize on both sides, max over ranks; `value` is the MEDIAN region, all five are listed under "runs" with
+the shader clock a one-lane probe kernel measured beside them.  After the timed regions the output of the LAST timed launch is
+checked for 32 channels against a float64 direct sum of the same FIR computed on the GPU ("parity_checked", "max_rel_err"); a
+failure prints NO line.  `--mode stream` runs one launch per step over a [channels, chunk] batch through the zero-copy ring, the
+real-time call pattern - by default with the library alternating its own two streams (adsp_ring_set_pipeline(2)); its figure is
+also measured after the timed region and reported under "stream" ("one_stream": every step on the caller's stream, with its
+per-kernel time and hipGraph replay; "resident": resident launches).  History is carried by the engine exactly as between
+reference apply() calls; every output sample of every step is produced inside the timed region.  Before the W warm-up steps the
+same workload runs untimed for --prewarm-ms (default 300 ms): an idle MI355X needs tens of milliseconds of sustained load before
+its shader clock has ramped up.
 
-For N > 1 (torchrun, one rank per GPU) every rank owns its own channel shard (weak scaling); the only collective is the
-RCCL broadcast of the filter spectrum before the timed region.
+For N > 1 every rank owns its own channel shard (weak scaling); the only collective is the RCCL broadcast of the filter spectrum
+before the timed region.  The driver launches one rank per GPU with torch.distributed.run; plain `python bench.py --gpus N` does
+the same by re-executing itself under that launcher; `--single-process` drives N GPUs from one process (adsp_bcast_spectrum).
 
 Prints ONE JSON line on rank 0 (driver contract) including
-  roofline     - algorithmic bytes (8 B/sample) / average KERNEL duration (HIP events around each kernel launch on the
-                 launch stream, adsp_kernel_time) vs the 8 TB/s HBM3E spec; traffic from profiles/traffic.json (PMC)
-  latency      - config 3 (CreateEQ3BandFFT, 2048 stereo pairs x 512 samples) us per step in the real-time call
-                 pattern, and the numpy-API .apply(chunk) us per call (PCIe / launch bound; never `value`)
+  roofline     - algorithmic bytes (8 B/sample) / average KERNEL duration of the median run (HIP events around each kernel launch
+                 on the launch stream, adsp_kernel_time) vs the 8 TB/s HBM3E spec; traffic from profiles/traffic.json (PMC)
+  runs         - the five timed regions: Msamples/s, ms per step, kernel us per launch, shader MHz; min / max / median / spread
+  latency      - config 3 (CreateEQ3BandFFT, 2048 stereo pairs x 512 samples) us per step: one launch per step, resident
+                 launches, and a LIVE SESSION (adsp_live_*: one persistent launch, a producer publishing step by step, the
+                 publication-to-output round trip); the numpy-API .apply(chunk) us per call (PCIe / launch bound; never `value`)
   cpu_baseline - the oracle's restatement of the reference (numpy) on the host cores: literal 3N complex and 2N real
                  variants, one process and one process per physical core; bounded sample.
 """
