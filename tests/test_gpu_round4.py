@@ -524,3 +524,27 @@ def test_library_pipelined_ring_steps_with_a_real_producer(adsp, n, kind, channe
     user.synchronize()
     assert float((y - t).abs().max()) <= 1e-5 * float(t.abs().max())
     eng.close()
+
+
+def test_unaligned_chunk_size_longer_than_one_transform_is_partitioned(adsp):
+    """N = 88202 (Example4's two seconds plus two samples: N % 4 == 2, 44100 taps): the kernel does not fit one 32768-point transform,
+    so the drop-in class runs partitioned engines - the later parts ADD to the output, which the dword-access kernel does in place
+    (accumulate mode 1)."""
+    import torch
+    from pyaudiodsptools_amd import PartitionedFirEngine
+    n, fs, steps = 88202, 44100, 3
+    adsp.config.initialize(fs, n)
+    dev = adsp.CreateLowCutFilter(120, channels=2)
+    assert isinstance(dev.engine, PartitionedFirEngine) and len(dev.engine.engines) >= 2
+    g = torch.Generator(device="cuda").manual_seed(88202)
+    x = torch.empty((steps, 2, n), device="cuda").uniform_(-1, 1, generator=g)
+    y = torch.empty_like(x)
+    s = torch.cuda.current_stream().cuda_stream
+    for k in range(steps):
+        dev.engine.apply_device(x[k], y[k], 1, s)
+    torch.cuda.synchronize()
+    t = _exact(adsp, dev.fir, x)
+    assert float((y - t).abs().max()) <= 1e-5 * float(t.abs().max())
+    dev2 = adsp.CreateLowCutFilter(120, channels=2)  # a fresh stream through the host path
+    yh = dev2.apply_batch(x[0].cpu().numpy())
+    assert np.abs(yh - t[0].cpu().numpy()).max() <= 1e-5 * float(t.abs().max())
