@@ -405,17 +405,12 @@ int set_device(const adsp_engine* e) {
     return ADSP_OK;
 }
 
-// async = false: blocking copies (the caller has drained the device: nothing is reading the tables).
-// async = true : the tables are staged in pinned memory and copied ON `stream`, i.e. after every launch already queued
-//                there and before every later one - no device-wide synchronisation, the filter changes between two steps.
 // The spectrum-stage tables of one plan: `tab` (per-thread rows) and `tab0` (the self-paired butterflies), from the spectrum H of
 // M + 1 bins.  Shared by the engine's own plan and by the plan a live session runs on (adsp_live_start).
 template <class R, class HT>
 void build_pair_tables(const PlanInfo& pl, int M, const HT* H, bool real_spec, std::vector<typename Vec<R>::T4>& tab,
                        std::vector<typename Vec<R>::T2>& tab0) {
     using V = Vec<R>;
-    using T2 = typename V::T2;
-    using T4 = typename V::T4;
     const int T = pl.T;
     const int RR = pl.rad[pl.NP - 1];        // radix of the paired passes: P for XL plans, P/2, P/4 .. otherwise
     const int D = M / RR;                     // bin spacing between a butterfly's outputs
@@ -471,6 +466,9 @@ void build_pair_tables(const PlanInfo& pl, int M, const HT* H, bool real_spec, s
     for (int r = 0; r < RR / 2; ++r) put0(2 + (RR / 2 - 1) + r, D / 2 + D * r);
 }
 
+// async = false: blocking copies (the caller has drained the device: nothing is reading the tables).
+// async = true : the tables are staged in pinned memory and copied ON `stream`, i.e. after every launch already queued
+//                there and before every later one - no device-wide synchronisation, the filter changes between two steps.
 template <class R, class HT>
 int upload_pairs_t(adsp_engine* e, const HT* H, hipStream_t stream, bool async) {
     using V = Vec<R>;
