@@ -173,3 +173,77 @@ def test_random_fused_volume_and_accumulate_against_the_exact_engine(seed):
     what = f"seed {seed}: N={n} {kind} taps={len(fir.taps)} C={channels} steps={steps} F={eng.geometry.fft_size} {opt} mode={mode} {db:.2f} dB"
     scale = max(float(truth.abs().max()) * 10 ** (db / 20), 0.1)
     assert float((y - want).abs().max()) <= 1e-5 * max(scale, 1.0), f"{what}: {float((y - want).abs().max()):.3e}"
+
+
+UNALIGNED = [5, 6, 10, 22, 30, 101, 250, 1001, 1002, 1999, 3001, 4410, 9999]
+
+
+@pytest.mark.parametrize("seed", range(60 * SCALE))
+def test_random_unaligned_chunk_sizes_against_the_exact_engine(seed):
+    """Round 4: chunk sizes that are NOT multiples of 4 (or shorter than 16 samples) - the dword-access form of the generic kernel:
+    cut filters with even and odd lengths, EQ composites, arbitrary kernels with random delays, ragged channels, every call
+    pattern incl. the zero-copy ring and host buffers, with and without the accumulating output."""
+    import torch
+    import pyaudiodsptools_amd as adsp
+    from pyaudiodsptools_amd import FirEngine, FirStream, design
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.choice(UNALIGNED))
+    fs = int(rng.choice([44100, 48000, 96000]))
+    kind = str(rng.choice(["lowcut", "highcut", "eq", "random"]))
+    if kind == "lowcut":
+        fir = FirStream(design.lowcut_kernel(float(rng.uniform(50, 2000)), fs, n), n)
+    elif kind == "highcut":
+        fir = FirStream(design.highcut_kernel(float(rng.uniform(3000, 0.45 * fs)), fs, n), n)
+    elif kind == "eq":
+        fir = FirStream(design.eq3_composite(100, float(rng.uniform(-6, 6)), 700, float(rng.uniform(-6, 6)), 8000, float(rng.uniform(-6, 6)), fs, n), n)
+    else:
+        m = int(rng.integers(1, max(2, n // 2)))
+        taps = rng.normal(size=m)
+        fir = FirStream(taps / np.abs(taps).sum(), n, latency_chunks=1, lookahead=int(rng.integers(0, max(1, n // 4))))
+    if not design.fits_one_transform(fir):
+        pytest.skip("kernel longer than one transform")
+    channels = int(rng.choice([1, 2, 3, 5, 17, 64, 70]))
+    steps = int(rng.integers(4, 12))
+    opt = str(rng.choice(["stream", "batch"]))
+    geo = design.overlap_save_geometry(fir, 0, opt)
+    ring = int(rng.choice([0, 0, geo.history_chunks + 3]))
+    eng = FirEngine(fir, channels=channels, optimize_for=opt, ring_slots=ring)
+    acc = bool(rng.random() < 0.3)
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=gen)
+    base = torch.empty_like(x).uniform_(-0.5, 0.5, generator=gen) if acc else torch.full_like(x, float("nan"))
+    y = base.clone()
+    if acc:
+        eng.set_accumulate(1)
+    s = torch.cuda.current_stream().cuda_stream
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    k = 0
+    while k < steps:
+        op = str(rng.choice(["dev1", "devk", "ring", "host"]))
+        cnt = 1 if op in ("dev1", "ring") else int(rng.integers(1, steps - k + 1))
+        if op == "host":
+            torch.cuda.synchronize()
+            buf = y[k:k + cnt].cpu().numpy().copy()   # (with accumulate on, the host call adds to what `out` holds)
+            lib_out = np.ascontiguousarray(buf)
+            from pyaudiodsptools_amd import _capi
+            xin = np.ascontiguousarray(x[k:k + cnt].cpu().numpy())
+            _capi.check(eng._lib.adsp_apply_host(eng._h, xin.ctypes.data_as(ctypes.c_void_p), lib_out.ctypes.data_as(ctypes.c_void_p), cnt))
+            y[k:k + cnt] = torch.from_numpy(lib_out).cuda()
+        elif op == "ring":
+            slot = eng.ring_acquire()
+            assert hip.hipMemcpyAsync(slot, x[k].data_ptr(), channels * n * 4, 3, s) == 0
+            eng.apply_ring(y[k], s)
+        else:
+            eng.apply_device(x[k:k + cnt], y[k:k + cnt], cnt, s)
+        k += cnt
+    torch.cuda.synchronize()
+    ex = adsp.ExactFirEngine(fir, channels=channels)
+    truth = torch.empty_like(x)
+    ex.apply_device(x, truth, steps, s)
+    torch.cuda.synchronize()
+    want = truth + base if acc else truth
+    scale = max(float(truth.abs().max()), 1e-3)
+    what = f"seed {seed}: N={n} {kind} taps={len(fir.taps)} C={channels} steps={steps} F={eng.geometry.fft_size} V={eng.block_outputs} {opt} ring={ring} acc={acc}"
+    assert bool(torch.isfinite(y).all()), what
+    assert float((y - want).abs().max()) <= 1e-5 * max(scale, 0.1), f"{what}: max|d| = {float((y - want).abs().max()):.3e}, scale {scale:.3e}"
