@@ -11,7 +11,8 @@ __global__ void live_publish_kernel(unsigned* seq, unsigned value) {
     __hip_atomic_fetch_max(seq, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// exchange buffers + the pass twiddles, which a session keeps in LDS when they fit beside eight workgroups per CU
+// exchange buffers + the pass twiddles, which a session keeps in LDS when they fit beside eight workgroups per CU; the plan with one
+// wave per channel (17 workgroups per CU) keeps rows 0 of the tables only and forms the other powers in registers
 template <class PL, int CPB>
 constexpr bool live_tw_in_lds() {
     return !PL::XL || PL::P >= 16;
@@ -19,7 +20,7 @@ constexpr bool live_tw_in_lds() {
 // ... and, for the 8-points-per-thread plan, the history rows (LQ quarter chunks of N = M samples per channel)
 template <class PL, int CPB, int LQ>
 constexpr int live_lds_bytes() {
-    return lds_bytes<PL, CPB>() + (live_tw_in_lds<PL, CPB>() ? PL::tw_total * (int)sizeof(real4) : 0) +
+    return lds_bytes<PL, CPB>() + (live_tw_in_lds<PL, CPB>() ? PL::tw_total : PL::tw1_total) * (int)sizeof(real4) +
            (PL::P <= 8 ? CPB * LQ * (PL::M / 4) * (int)sizeof(float) : 0);
 }
 
