@@ -430,13 +430,18 @@ void build_pair_tables(const PlanInfo& pl, int M, const HT* H, bool real_spec, s
         for (int u = 0; u < PU; ++u)
             for (int g = 0; g < npairs / 4; ++g)
                 for (int tid = 0; tid < T; ++tid) {
-                    if (self_paired(tid, u)) continue;
+                    // XL plans with 8 points per thread run the two self-paired butterflies through the regular pair operations
+                    // (spectrum_stage_xl): lane 32 (bins D/2 + D r, partner 7-r in the same lane) takes rows like any other lane;
+                    // lane 0 (bins D r) too, except pair 0 = the bins 0 and M/2, each its own partner: (c1(0), c1(M/2), Im c2(0))
+                    const bool in_lane = pl.XL && RR == 8 && self_paired(tid, u);
+                    if (self_paired(tid, u) && !in_lane) continue;
                     for (int q = 0; q < 4; ++q) {
                         const PairEntry<R> pe = pair_entry<R>(H, M, first_bin(tid, u) + D * (4 * g + q));
                         flat[3 * q + 0] = pe.wc.x;
                         flat[3 * q + 1] = pe.g2.x;
                         flat[3 * q + 2] = pe.g1.y;
                     }
+                    if (in_lane && tid == 0) flat[1] = pair_entry<R>(H, M, M / 2).wc.x;
                     for (int j = 0; j < 3; ++j)
                         tab[((size_t)(u * (npairs / 4) + g) * 3 + j) * T + tid] =
                             V::m4(flat[4 * j], flat[4 * j + 1], flat[4 * j + 2], flat[4 * j + 3]);
@@ -445,9 +450,14 @@ void build_pair_tables(const PlanInfo& pl, int M, const HT* H, bool real_spec, s
     for (int u = 0; u < PU && !real_spec; ++u)
         for (int h = 0; h < npairs / 2; ++h)
             for (int tid = 0; tid < T; ++tid) {
-                if (self_paired(tid, u)) continue;  // self-paired butterflies: tab0
-                const PairEntry<R> a = pair_entry<R>(H, M, first_bin(tid, u) + D * (2 * h));
+                const bool in_lane = pl.XL && RR == 8 && self_paired(tid, u);  // (as above)
+                if (self_paired(tid, u) && !in_lane) continue;                  // self-paired butterflies: tab0
+                PairEntry<R> a = pair_entry<R>(H, M, first_bin(tid, u) + D * (2 * h));
                 const PairEntry<R> b = pair_entry<R>(H, M, first_bin(tid, u) + D * (2 * h + 1));
+                if (in_lane && tid == 0 && h == 0) {  // bins 0 and M/2: c4 <- conj(c1(M/2)), which then multiplies register 4
+                    const PairEntry<R> m = pair_entry<R>(H, M, M / 2);
+                    a.g2 = V::m2(m.wc.x, -m.wc.y);
+                }
                 const size_t row = (size_t)(u * (npairs / 2) + h) * 3;
                 tab[(row + 0) * T + tid] = V::m4(a.wc.x, a.wc.y, a.g1.x, a.g1.y);
                 tab[(row + 1) * T + tid] = V::m4(a.g2.x, a.g2.y, b.wc.x, b.wc.y);
@@ -1999,6 +2009,12 @@ int adsp_live_stop(adsp_engine* e, unsigned* steps_consumed) {
             seg[5] += (double)(L.trace[(st + 1) * 8] - t[5]);
             ++n;
         }
+        if (n && getenv("ADSP_LIVE_TRACE_RAW"))
+            for (int st = 1; st < 25; ++st) {
+                const unsigned long long* t = L.trace + st * 8;
+                fprintf(stderr, "  step +%d: %llu %llu %llu %llu %llu | next top %llu\n", st, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4],
+                        L.trace[(st + 1) * 8] - t[5]);
+            }
         if (n)
             fprintf(stderr, "libadsp live trace (workgroup 1, %d steps, shader cycles): wait+request %.0f | chunk arrives %.0f | window %.0f | transform %.0f | "
                     "confirm+stores %.0f | tail %.0f | step %.0f\n", n, seg[0] / n, seg[1] / n, seg[2] / n, seg[3] / n, seg[4] / n, seg[5] / n,
