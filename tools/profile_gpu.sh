@@ -19,6 +19,7 @@ for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE GRBM_COUNT" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   i=$((i+1))
   [ $i -gt $PASSES ] && break
+  if [ -n "${PROF_ONLY:-}" ]; then case " $PROF_ONLY " in *" $i "*) ;; *) continue;; esac; fi  # e.g. PROF_ONLY="4 5": the HBM traffic passes only
   rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/pmc$i -o p -- $BENCH > $OUT/pmc$i.log 2>&1
 done
 python3 - "$OUT" <<'PY'
