@@ -26,7 +26,7 @@ torch.cuda.synchronize()
 out = torch.empty((8, C, N), device=dev)
 prod = torch.cuda.Stream()
 res = []
-for how in ("host", "stream", "host", "stream"):
+for how in os.environ.get("LIVE_PRODUCERS", "host,stream,host,stream").split(","):  # PMC passes: "host,host" (rocprofv3 serialises kernels: no publishing kernel can run beside the session)
     eng.live_start(out, 8, steps, None)
     time.sleep(0.002)
     t0 = time.perf_counter()
