@@ -346,6 +346,12 @@ class Runner:
                     probe = ClockProbe(torch.cuda.current_device(), 10000.0, probe_stream.cuda_stream)
                 except Exception:
                     probe = None
+            # every stream the steps were issued on (not the whole device: the clock probe's 10 ms run beside them) - torch's streams
+            # are non-blocking, so the current stream alone says nothing about work on the pipelined run's caller stream (joined
+            # with the library's two streams by adsp_ring_join) or on the side streams of --streams 2
+            for st in [getattr(self, "user_stream", None)] + list(getattr(self, "side_streams", [])):
+                if st is not None:
+                    st.synchronize()
             torch.cuda.current_stream().synchronize()
             wall = time.perf_counter() - t0
             torch.cuda.synchronize()
