@@ -332,3 +332,13 @@ def test_traffic_stamp_follows_the_kernel_code_not_its_comments(tmp_path):
     traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     stamped = [k for k, v in traffic.items() if isinstance(v, dict) and "kernel_sha16" in v]
     assert "lowcut_4096x4096_batch" in stamped and all(len(traffic[k]["kernel_sha16"]) == 16 for k in stamped)
+    # every stamped entry names the committed rocprofv3 summary it was folded from, and that file holds both traffic passes
+    for k in stamped:
+        summary = os.path.join(ROOT, traffic[k]["source"])
+        assert os.path.isfile(summary), (k, traffic[k]["source"])
+        txt = open(summary).read()
+        assert "FETCH_SIZE" in txt and "WRITE_SIZE" in txt, summary
+    if traffic["lowcut_4096x4096_batch"]["kernel_sha16"] != base:  # not an error here: bench.py then reports traffic: null and says why
+        import warnings
+        warnings.warn("profiles/traffic.json was measured on other kernel sources than this tree's: re-run tools/sessions/r4_session25.sh "
+                      "and tools/update_traffic.py before quoting a traffic figure")
