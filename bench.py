@@ -88,6 +88,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stream-extra", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 4 and 5 (per-GPU shapes), which follow the headline in the same line")
     ap.add_argument("--no-graph", action="store_true", help="stream mode: do not try the hipGraph replay")
     ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
                     help="stream mode: 2 (default) = adsp_ring_set_pipeline(2): the LIBRARY runs consecutive steps on its own two streams in "
@@ -125,6 +126,24 @@ def kernel_sha16(csrc=None):
     return h.hexdigest()[:16]
 
 
+def traffic_record(key, cps):
+    """HBM bytes per launch from profiles/traffic.json (rocprofv3 PMC passes, tools/profile_gpu.sh), scaled to `cps` chunks per launch;
+    (None, reason) when there is no record or it was measured on other kernel sources (the records are stamped, kernel_sha16)."""
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tf):
+        return None, None
+    try:
+        rec = json.load(open(tf)).get(key)
+        if rec and rec.get("kernel_sha16") != kernel_sha16():
+            return None, (f"null: {rec.get('source')} was measured on kernel sources {rec.get('kernel_sha16', 'unstamped')}, "
+                          f"this run is {kernel_sha16()} (re-run tools/profile_gpu.sh + tools/update_traffic.py)")
+        if rec:  # measured per launch at rec["steps_per_launch"] chunks; traffic is linear in the chunk count
+            return int(rec["hbm_bytes_per_launch"] * (cps / rec.get("steps_per_launch", cps))), rec.get("source")
+    except Exception:
+        pass
+    return None, None
+
+
 def make_fir(args):
     from pyaudiodsptools_amd import design
     n, fs = args.chunk, args.fs
@@ -147,7 +166,10 @@ def cpu_baseline(args):
                       f"physical core over disjoint channels, {args.cpu_seconds:.0f} s per process, chunks of {args.chunk} samples; "
                       f"{m['cpu_model']}, {cores} physical cores / {m['logical_cpus']} logical"
                       + (f", container CPU quota {m['cgroup_cpu_quota']:.1f} CPUs" if m.get("cgroup_cpu_quota") else "")
-                      + (f", load average before the run {m['loadavg_before']:.1f}" if "loadavg_before" in m else ""),
+                      + (f", load average before the run {m['loadavg_before']:.1f}" if "loadavg_before" in m else "")
+                      + (f", {m['busy_cpus_at_start']} CPUs busy when it started (waited {m['waited_for_quiet_s']:.0f} s for a quiet box: "
+                         f"{'quiet' if m.get('quiescent') else 'STILL UNDER LOAD - measured twice, the better run stands'})" if m.get("busy_cpus_at_start") is not None else ""),
+            "load": {k: m.get(k) for k in ("loadavg_before", "busy_cpus_at_start", "waited_for_quiet_s", "quiescent", "literal3n_allcores_runs") if k in m},
             "variants_msamples_s": {"literal_3n_complex_1_process": m["literal3n_1proc"],
                                     f"literal_3n_complex_{cores}_processes": m["literal3n_allcores"],
                                     "rfft_2n_1_process_16ch_batches": m["rfft2n_1proc"],
@@ -188,23 +210,28 @@ class Runner:
                               "tremolo": effects.CreateTremolo}[args.effect]())
         self.stream = torch.cuda.current_stream(dev)
         sptr = self.stream.cuda_stream
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(1234 + rank)
         amp = float(os.environ.get("ADSP_BENCH_AMPLITUDE", "1"))  # tuning only: 0 = all-zero data (DVFS check)
         s16 = args.io != "f32"
         dt = torch.int16 if s16 else torch.float32
         self.graph = None
+        # SURVEY 8d: counter-based generator, sample = f(seed 1234, GLOBAL channel, absolute sample index) - the device kernel behind
+        # adsp_synth_device; pyaudiodsptools_amd/synth.py regenerates any channel on the host (oracle_check below)
+        from pyaudiodsptools_amd import synth as asynth
+        self.seed, self.first_channel, self.amp = 1234, rank * C, amp
 
-        def synth(shape):
-            if s16:  # uniform 16-bit PCM at -6 dBFS
-                return torch.randint(-16384, 16384, shape, device=dev, dtype=torch.int16, generator=gen)
-            return torch.empty(shape, device=dev, dtype=torch.float32).uniform_(-amp, amp, generator=gen)
+        def synth(shape, first_sample):
+            """[steps, C, N] (or [C, N]): channel c of this rank = global channel rank * C + c, first sample = absolute index first_sample"""
+            t = torch.empty(shape, device=dev, dtype=dt)
+            steps_ = shape[0] if len(shape) == 3 else 1
+            asynth.fill_device(t, self.seed, self.first_channel, first_sample, C, N, steps_, "s16" if s16 else "f32", amp, dev.index,
+                               torch.cuda.current_stream(dev).cuda_stream)
+            return t
         if stream_mode:
             # zero-copy streaming: the synthetic producer has filled every ring slot before the timed region
             # (apply_device copies each batch into the ring and advances it; setup only)
             scratch = torch.empty((C, N), device=dev, dtype=dt)
-            for _ in range(eng.ring_slots):
-                batch = synth((C, N))
+            for k_fill in range(eng.ring_slots):
+                batch = synth((C, N), k_fill * N)
                 eng.apply_device(batch, scratch, 1, sptr)
                 torch.cuda.synchronize(dev)
             self.outs = [torch.empty((C, N), device=dev, dtype=dt) for _ in range(4)]
@@ -262,7 +289,7 @@ class Runner:
             self.samples_per_step = cps * C * N
             # distinct resident input batches, > 256 MiB in total so the Infinity Cache cannot hold them
             n_in = max(2, min(8, -(-(768 << 20) // (cps * C * N * 4))))
-            self.ins = [synth((cps, C, N)) for _ in range(n_in)]
+            self.ins = [synth((cps, C, N), i * cps * N) for i in range(n_in)]  # batch i: absolute samples i * cps * N .. of every channel
             self.outs = [torch.empty((cps, C, N), device=dev, dtype=dt) for _ in range(2)]
 
             self.n_in = n_in
@@ -405,6 +432,42 @@ class Runner:
         ex.close()
         return {"max_rel_err": err / max(scale, 1e-30), "max_abs_err": err, "scale": scale, "channels": len(chans), "samples": int(got.numel()),
                 "launch": j, "against": "adsp_exact_* float64 direct sum on the same input batch (history = tail of the previous batch)"}
+
+
+    def oracle_check(self, fir, chunks=3):
+        """The same output once more, checked on the HOST against the CPU oracle (oracle/fftfilter_oracle.direct_stream_convolution:
+        float64, no FFT) for the first and the last channel: the head and the tail of the LAST timed launch's output batch.  Possible
+        without copying the batch back because the timed input is a pure function of (seed, channel, absolute sample index)
+        (pyaudiodsptools_amd/synth.py regenerates those channels).  float32 batches only."""
+        if self.mode == "stream" or self.step_count < 2 or self.eng.sample_format != "f32":
+            return None
+        from oracle import fftfilter_oracle as orc
+        from pyaudiodsptools_amd import synth as asynth
+        j = self.step_count - 1
+        bi, bp = j % self.n_in, (j - 1) % self.n_in
+        C, N, cps = self.C, self.N, self.cps
+        hist = self.eng.geometry.history_chunks
+        k = max(1, min(chunks, cps))
+        y = self.outs[j % 2]
+        err = scale = 0.0
+        n_samples = 0
+        chans = sorted({0, C - 1})
+        for c in chans:
+            gc = self.first_channel + c
+            segs = [(np.concatenate([asynth.uniform_host(self.seed, gc, (bp * cps + cps - hist) * N, hist * N, self.amp),
+                                     asynth.uniform_host(self.seed, gc, bi * cps * N, k * N, self.amp)]), 0)]
+            if cps >= 2 * k + hist:  # the tail of the batch: its history lies inside the same batch
+                segs.append((asynth.uniform_host(self.seed, gc, (bi * cps + cps - k - hist) * N, (k + hist) * N, self.amp), cps - k))
+            for stream, first_chunk in segs:
+                ref = orc.direct_stream_convolution(fir.taps, stream, N, fir.latency_chunks, fir.lookahead)[hist * N:]
+                got = y[first_chunk:first_chunk + k, c].reshape(-1).float().cpu().numpy().astype(np.float64)
+                err = max(err, float(np.abs(got - ref).max()))
+                scale = max(scale, float(np.abs(ref).max()))
+                n_samples += ref.size
+        return {"max_rel_err": err / max(scale, 1e-30), "max_abs_err": err, "scale": scale, "channels": [self.first_channel + c for c in chans],
+                "samples": n_samples, "launch": j,
+                "against": "oracle/fftfilter_oracle.direct_stream_convolution (float64 numpy, no FFT) on the host, input regenerated by "
+                           "pyaudiodsptools_amd/synth.py from (seed, channel, absolute sample index): head and tail chunks of the last timed launch"}
 
 
 def stream_figures(args, fir, dev, local_rank, world, rank, alg_bytes, channels=None, chunk=None, steps=2048):
@@ -711,6 +774,8 @@ def main():
                     runners[i].measure(steps, warm, gate.wait, prewarm_ms, repeats=repeats, clock=clock and i == 0)
                     if not args.no_parity_check:
                         parity[i] = runners[i].parity_check(fir_x)
+                        if parity[i] is not None:
+                            parity[i]["oracle"] = runners[i].oracle_check(fir_x)
                 except BaseException as exc:  # a dead thread must not leave the others at the barrier
                     errors.append(exc)
                     gate.abort()
@@ -732,13 +797,19 @@ def main():
         r.measure(steps, warm, barrier, prewarm_ms, repeats=repeats, clock=clock)
         runs = r.last_runs
         pblock = None if args.no_parity_check else r.parity_check(fir_x)
+        if pblock is not None:
+            pblock["oracle"] = r.oracle_check(fir_x)  # every rank checks two of ITS channels against the CPU oracle
         if barrier is not None:
-            t = torch.tensor([x for run in runs for x in run[:2]] + [pblock["max_rel_err"] if pblock else 0.0], device=red_dev, dtype=torch.float64)
+            orc_err = pblock["oracle"]["max_rel_err"] if pblock and pblock.get("oracle") else 0.0
+            t = torch.tensor([x for run in runs for x in run[:2]] + [pblock["max_rel_err"] if pblock else 0.0, orc_err], device=red_dev, dtype=torch.float64)
             tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
             runs = [(float(t[2 * k]), float(t[2 * k + 1]), runs[k][2], runs[k][3]) for k in range(len(runs))]
             if pblock:
-                pblock["max_rel_err"] = float(t[-1])
+                pblock["max_rel_err"] = float(t[-2])
                 pblock["reduced"] = "max over ranks"
+                if pblock.get("oracle"):
+                    pblock["oracle"]["max_rel_err"] = float(t[-1])
+                    pblock["oracle"]["reduced"] = "max over ranks (channels listed: rank 0's)"
         return r, runs, pblock
 
     main_run, runs, parity = measure_everywhere(args, args.mode, fir, args.steps, args.warmup, args.prewarm_ms, args.runs, True)
@@ -767,6 +838,20 @@ def main():
                                           "of": "adsp_get_spectrum of every rank's engine"}
         if os.environ.get("ADSP_BENCH_REEXEC") == "1":
             dist_info["launcher"] = "bench.py re-executed itself under torch.distributed.run (plain `python3 bench.py --gpus N`)"
+        # A world of the wrong size, or a rank that ended up with another filter, must not produce a line the driver could take for an N-GPU
+        # measurement: every rank sees the same gathered values, so every rank leaves here - non-zero exit status, NO JSON line.
+        want = int(os.environ.get("ADSP_BENCH_EXPECT_RANKS", args.gpus))  # (the env override exists for the test of this very exit)
+        if dist_info["ranks_seen"] != want or not dist_info["spectrum_checksum"]["equal_on_all_ranks"]:
+            sys.stderr.write(f"bench.py: rank {rank}: the job is not what --gpus {args.gpus} asked for: ranks_seen = {dist_info['ranks_seen']} (expected {want}), "
+                             f"spectrum checksums {'equal' if dist_info['spectrum_checksum']['equal_on_all_ranks'] else 'DIFFER'} across ranks "
+                             f"({[f'{v & 0xFFFFFFFFFFFFFFFF:016x}' for v in sums]}) - no line\n")
+            sys.stderr.flush()
+            if barrier is not None:
+                try:
+                    tdist.destroy_process_group()
+                except Exception:
+                    pass
+            os._exit(3)
     # The same collective through the C ABI (adsp_bcast_spectrum_rank: RCCL opened by libadsp, ncclCommInitRank, the id handed over
     # through a file) as a cross-check on real multi-GPU hardware: a small engine per rank, every rank starts from zeros except
     # rank 0, checksums gathered.  Fenced by a thread + time-out - it may not cost the driver its line.
@@ -814,6 +899,10 @@ def main():
         if not (ok and parity["scale"] > 0.05):
             raise SystemExit(f"bench.py: PARITY FAILURE in the timed output: max|d| / max|truth| = {parity['max_rel_err']:.3e} > {tol} "
                              f"({parity['channels']} channels x {parity['samples'] // max(1, parity['channels'])} samples against the float64 direct sum) - no line")
+        oc = parity.get("oracle")
+        if oc is not None and not (oc["max_rel_err"] <= tol and oc["scale"] > 0.05):
+            raise SystemExit(f"bench.py: PARITY FAILURE in the timed output against the CPU oracle: max|d| / max|ref| = {oc['max_rel_err']:.3e} > {tol} "
+                             f"(channels {oc['channels']}, {oc['samples']} samples) - no line")
     sps, cps = main_run.samples_per_step, main_run.cps
     eng_desc = {"fft_size": main_run.eng.geometry.fft_size, "real": main_run.eng.real_spectrum,
                 "kept": N if args.mode == "stream" else main_run.eng.block_outputs, "taps": len(fir.taps)}
@@ -862,11 +951,13 @@ def main():
         except Exception as exc:
             latency = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
-    # BASELINE.json's own 8-GPU configurations, per-GPU shapes, after the headline (N > 1 only, so that the N = 1 line of
-    # a scaling run is the BENCH line): configs[3] HighCut(8000) on 8192 channels x 4096 per GPU, configs[4] the fused
-    # LowCut -> EQ3 -> HighCut chain @ 96 kHz on 4096 channels x 8192 per GPU.  Same step definition, same timing rules.
+    # BASELINE.json's own 8-GPU configurations at their PER-GPU shapes, after the headline and with the same rules (W warm-up launches,
+    # three timed regions between barriers, median, kernel time from HIP events around every launch, the last timed output checked
+    # against the float64 direct sum and against the CPU oracle): configs[3] HighCut(8000) on 8192 channels x 4096 per GPU, configs[4]
+    # the fused LowCut -> EQ3 -> HighCut chain @ 96 kHz on 4096 channels x 8192 per GPU.  Round 5: at EVERY N, the driver's N = 1 run
+    # included, so that their roofline fractions are driver-timed numbers.
     extra_configs = None
-    if (barrier is not None or args.single_process) and world > 1 and args.mode == "batch" and args.io == "f32" and args.effect == "none":
+    if args.mode == "batch" and args.io == "f32" and args.effect == "none" and args.filter == "lowcut" and not args.no_configs:
         extra_configs = {}
         try:
             for r in [main_run] + getattr(main_run, "peers", []):
@@ -874,25 +965,39 @@ def main():
             torch.cuda.empty_cache()
         except AttributeError:
             pass
+        small = ["--channels", "256", "--chunks-per-step", "12"] if (getattr(args, "small", False) or args.channels < 1024) else None  # (test shapes stay small)
         for key, argv in (("config4_highcut_8192ch_x_4096", ["--filter", "highcut", "--channels", "8192", "--chunk", "4096", "--fs", "44100"]),
                           ("config5_chain_4096ch_x_8192_96k", ["--filter", "chain", "--channels", "4096", "--chunk", "8192", "--fs", "96000"])):
             try:
-                ax = parse(argv)
+                ax = parse(argv + (small or []))
                 x_steps = max(2, min(args.steps, 8))
                 rx, x_runs, x_par = measure_everywhere(ax, "batch", make_fir(ax), x_steps, 2, min(args.prewarm_ms, 150.0), 3, False)
                 x_med, x_block = summarize_runs(x_runs, rx.samples_per_step * world, x_steps)
                 x_wall, x_kern, x_launches, _ = x_runs[x_med]
                 per = x_kern / 1e3 / x_launches
+                x_alg = ALG_BYTES_PER_SAMPLE * rx.samples_per_step
+                x_traffic, x_src = traffic_record(f"{ax.filter}_{ax.channels}x{ax.chunk}_batch", rx.cps)
+                x_orc = (x_par or {}).get("oracle")
                 extra_configs[key] = {"value": round(rx.samples_per_step * world * x_steps / x_wall / 1e6, 1), "unit": "Msamples/s", "n_gpus": world,
-                                      "steps": x_steps, "ms_per_step": round(x_wall * 1e3 / x_steps, 4),
+                                      "steps": x_steps, "warmup": 2, "runs": 3, "ms_per_step": round(x_wall * 1e3 / x_steps, 4),
                                       "workload": f"{FILTER_NAMES[ax.filter]} @ {ax.fs} Hz, {ax.channels} channels x {ax.chunk}-sample chunks per GPU, "
-                                                  f"{rx.cps} chunks per step, {rx.eng.block_outputs} of {rx.eng.geometry.fft_size} samples kept per transform",
-                                      "roofline_frac": round(ALG_BYTES_PER_SAMPLE * rx.samples_per_step / per / 1e9 / HBM_PEAK_GBS, 4),
+                                                  f"{rx.cps} chunks per step, {rx.eng.block_outputs} of {rx.eng.geometry.fft_size} samples kept per transform, "
+                                                  f"{len(rx.eng.fir.taps)} taps",
+                                      "roofline": {"bound": "hbm", "achieved": round(x_alg / per / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                   "frac": round(x_alg / per / 1e9 / HBM_PEAK_GBS, 4), "traffic": x_traffic, "traffic_source": x_src,
+                                                   "kernel": "adsp::fftconv_kernel", "avg_launch_us": round(per * 1e6, 2), "launches": x_launches,
+                                                   "algorithmic_bytes_per_launch": int(x_alg)},
+                                      "roofline_frac": round(x_alg / per / 1e9 / HBM_PEAK_GBS, 4),
                                       "avg_launch_us": round(per * 1e6, 2),
                                       "runs_msamples_s": x_block["value_msamples_s"],
-                                      "parity_max_rel_err": None if not x_par else float(f"{x_par['max_rel_err']:.3e}")}
-                if x_par and not x_par["max_rel_err"] <= 1e-5:
-                    extra_configs[key]["error"] = "PARITY FAILURE against the float64 direct sum"
+                                      "parity_checked": x_par is not None,
+                                      "parity_max_rel_err": None if not x_par else float(f"{x_par['max_rel_err']:.3e}"),
+                                      "oracle_max_rel_err": None if not x_orc else float(f"{x_orc['max_rel_err']:.3e}")}
+                if small:
+                    extra_configs[key]["small"] = True
+                if (x_par and not x_par["max_rel_err"] <= 1e-5) or (x_orc and not x_orc["max_rel_err"] <= 1e-5):
+                    extra_configs[key] = {"error": "PARITY FAILURE against the float64 direct sum / the CPU oracle",
+                                          "parity_max_rel_err": extra_configs[key]["parity_max_rel_err"], "oracle_max_rel_err": extra_configs[key]["oracle_max_rel_err"]}
                 for r in [rx] + getattr(rx, "peers", []):
                     del r.ins, r.outs
                 del rx
@@ -905,21 +1010,7 @@ def main():
         samples_per_launch = sps * steps / launches
         achieved = alg_bytes * samples_per_launch / per_launch_s / 1e9
         mode_key = "stream" if args.mode == "stream" else "batch"
-        traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                key = f"{args.filter}_{C}x{N}_{mode_key}" + ("" if args.io == "f32" else "_s16")
-                rec = json.load(open(tf)).get(key)
-                if rec and rec.get("kernel_sha16") != kernel_sha16():
-                    # the counters were collected on a different build of the kernel: stale, so not reported
-                    traffic_src = (f"null: {rec.get('source')} was measured on kernel sources {rec.get('kernel_sha16', 'unstamped')}, "
-                                   f"this run is {kernel_sha16()} (re-run tools/profile_gpu.sh + tools/update_traffic.py)")
-                elif rec:  # measured per launch at rec["steps_per_launch"] chunks; scale by the chunk count (traffic is linear in it)
-                    traffic = int(rec["hbm_bytes_per_launch"] * (cps / rec.get("steps_per_launch", cps)))
-                    traffic_src = rec.get("source")
-            except Exception:
-                traffic = None
+        traffic, traffic_src = traffic_record(f"{args.filter}_{C}x{N}_{mode_key}" + ("" if args.io == "f32" else "_s16"), cps)
         line = {
             "metric": f"Msamples/s ({'float32' if args.io == 'f32' else 'int16 PCM'}, {N}-pt OLA FFT filter)",
             "value": round(value, 1),
@@ -952,7 +1043,11 @@ def main():
         line["parity_checked"] = parity is not None
         if parity is not None:
             line["max_rel_err"] = float(f"{parity['max_rel_err']:.3e}")
+            oc = parity.pop("oracle", None)
             line["parity"] = {k: (float(f"{v:.4e}") if isinstance(v, float) else v) for k, v in parity.items()}
+            if oc is not None:
+                line["oracle_checked"] = True
+                line["oracle_check"] = {k: (float(f"{v:.4e}") if isinstance(v, float) else v) for k, v in oc.items()}
         line.update(dist_info)
         if carrier:
             line["spectrum_carrier"] = carrier

@@ -41,7 +41,7 @@ extern "C" {
 #define ADSP_API
 #endif
 
-#define ADSP_ABI_VERSION 8
+#define ADSP_ABI_VERSION 9
 #define ADSP_MAX_HISTORY 8
 
 typedef enum adsp_status {
@@ -164,10 +164,20 @@ ADSP_API int adsp_bcast_spectrum(adsp_engine* const* engines, int n, int root);
  * broadcast carries the root's geometry, sample format, spectrum precision and kernel-reach hint (a rank whose engine was
  * built for another window layout fails with ADSP_ERR_ARG instead of filtering with the wrong offsets), the spectrum
  * follows, and each rank rebuilds its tables from what the collective left in its own memory.  A float64 spectrum
- * (adsp_set_spectrum_f64) travels as float64 in both forms of the collective.  Set-up path: the device is drained. */
+ * (adsp_set_spectrum_f64) travels as float64 in both forms of the collective.  Set-up path: the device is drained.
+ * The OUTCOME is collective as far as this library can make it: every rank enters both broadcasts whatever is wrong with its own
+ * engine.  A root without a spectrum says so in the header and EVERY rank returns ADSP_ERR_STATE without entering the second
+ * broadcast; a rank whose geometry differs still receives the spectrum (into scratch memory of the root's size, dropped) and only
+ * then returns ADSP_ERR_ARG, so the other ranks complete.  A rank whose call fails BEFORE the first broadcast (NULL / out-of-range
+ * arguments, no device, RCCL missing) or inside RCCL cannot be waited out by the others: treat any failure of this call on any
+ * rank as fatal for the job (abort all ranks) - which is why the launcher-side checks (bench.py: ranks_seen, spectrum checksum)
+ * exist.  Threads: the communicator table is locked only while it is read or written, never across ncclCommInitRank or the
+ * broadcast, so several ranks may be driven from threads of one process.  adsp_rccl_finalize destroys every communicator the
+ * library has built (no broadcast may be in flight); without it they live until the process ends. */
 #define ADSP_RCCL_UNIQUE_ID_BYTES 128
 ADSP_API int adsp_rccl_unique_id(char* unique_id /* [ADSP_RCCL_UNIQUE_ID_BYTES] */);
 ADSP_API int adsp_bcast_spectrum_rank(adsp_engine* engine, const char* unique_id, int rank, int world, int root);
+ADSP_API int adsp_rccl_finalize(void);
 /* The spectrum this engine's tables were last built from, n_bins = F/2+1 interleaved (re, im) float32 values - after a
  * broadcast: what the collective left in this engine's device memory (bench.py checksums it across ranks). */
 ADSP_API int adsp_get_spectrum(const adsp_engine* engine, float* spectrum_interleaved, int n_bins);
@@ -335,6 +345,13 @@ ADSP_API int adsp_ring_resident_status(adsp_engine* engine, int* timed_out);
  * session timed out), and streams of another priority come from another pool of queues.  A caller-provided stream must be
  * non-blocking and must not share a hardware queue with any stream that feeds the session.  Available for float32 engines in the stream geometry (power-of-two chunk 128 ..
  * 4096, fft_size = 2 x chunk_size) with lookback 5/4 N (the cut filters) or 7/4 N (the 3-band EQ); no fused effect.
+ * Output ring: step s overwrites slot s % out_slots of d_out whether or not anybody has read step s - out_slots; only the INPUT
+ * ring has flow control (adsp_live_slot).  The consumer keeps up to within out_slots steps of the producer - e.g. by reading step s
+ * before it publishes step s + out_slots, which a producer that waits for adsp_live_progress >= s + 1 before handing out slot
+ * s + out_slots does by construction - or sizes out_slots for the whole session.
+ * While a session runs the engine's other entry points that would touch the ring or the kernel's configuration are refused with
+ * ADSP_ERR_STATE (per-step, multi-step and resident calls, adsp_ring_produce_*, adsp_set_accumulate, adsp_set_epilogue, the
+ * spectrum setters, reset / state calls): adsp_live_stop first.
  * While a session runs, anything that drains the whole device waits for it: hipDeviceSynchronize, and the set-up calls of this
  * library that contain one (adsp_set_spectrum, adsp_reset, adsp_get_state / adsp_set_state, adsp_destroy of ANY engine on the
  * device) - stop the session first, or do the set-up before it starts.
@@ -474,6 +491,17 @@ ADSP_API int adsp_exact_reset(adsp_exact* fir); /* history back to zeros */
 /* d_in / d_out: device [n_steps][n_channels][chunk_size], NOT aliased; asynchronous on `stream` */
 ADSP_API int adsp_exact_apply_device(adsp_exact* fir, const void* d_in, void* d_out, int n_steps, void* stream);
 ADSP_API int adsp_exact_apply_host(adsp_exact* fir, const void* in, void* out, int n_steps);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Counter-based synthetic input: sample (channel c, absolute index t) is a pure function of (seed, c, t) -
+ * uniform(-1, 1) float32 (2^24 equidistant values, scaled by `amplitude`) or uniform int16 in [-16384, 16384) - written on the
+ * device straight into a [n_steps][n_channels][chunk_size] batch whose first sample of channel j is absolute index first_sample
+ * of channel first_channel + j.  pyaudiodsptools_amd/synth.py holds the bit-identical numpy twin, so a host-side checker can
+ * regenerate any channel of a resident batch (bench.py checks its timed output against the CPU oracle that way).
+ * chunk_size must be a multiple of 4.  Asynchronous on `stream`.
+ * ------------------------------------------------------------------------------------------------------------- */
+ADSP_API int adsp_synth_device(int device_id, unsigned seed, unsigned first_channel, unsigned long long first_sample, int n_channels,
+                               int chunk_size, int n_steps, int sample_format, float amplitude, void* d_out, void* stream);
 
 #ifdef __cplusplus
 }

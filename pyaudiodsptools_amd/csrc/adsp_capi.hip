@@ -23,6 +23,7 @@ int rccl_broadcast(float* const* d_buf, const int* devs, const hipStream_t* stre
 int rccl_version(int* version);
 int rccl_unique_id(char* out);
 int rccl_broadcast_rank(const char* unique_id, int rank, int world, int root, int dev, float* d_buf, size_t count, hipStream_t stream);
+int rccl_finalize();
 }  // namespace adsp
 
 // standalone elementwise form of the fused output effects (fftconv_kernel.hpp::epilogue_value): out[i] = effect(in[i]);
@@ -181,7 +182,9 @@ int check_geometry(int N, int F, int fmt, const PlanInfo** out, bool* generic) {
     if (three && !special) return fail(ADSP_ERR_ARG, "fft_size %d = 3 * 2^k is only available as 1.5 x chunk_size", F);
     const PlanInfo* p = special ? find_plan(F / 2, 4 * F / N, fmt) : find_plan_any_fn(F / 2, fmt);
     if (!p) return fail(ADSP_ERR_ARG, "no kernel plan for %d complex points", F / 2);
-    if (unaligned_chunk(N) && !p->launch_unaligned) return fail(ADSP_ERR_STATE, "internal: no dword-access kernel for %d complex points", F / 2);
+    if (unaligned_chunk(N) && !p->launch_unaligned)
+        return fail(ADSP_ERR_ARG, "chunk_size %d is not a multiple of 4 (or < 16): the plan selected for %d complex points has no dword-access kernel (a tuning "
+                    "plan chosen with ADSP_PLAN_VARIANT, or an int16 / fused-effect table): use the default float32 plans for such chunk sizes", N, F / 2);
     if (out) *out = p;
     if (generic) *generic = !special;
     return ADSP_OK;
@@ -997,6 +1000,10 @@ int adsp_rccl_unique_id(char* unique_id) {
 }
 
 // The same collective for a ONE-PROCESS-PER-GPU job: this process holds rank `rank` of `world`.
+// Both collectives (header, spectrum) are entered by EVERY rank whatever a rank finds wrong with its own engine - a rank that
+// returned early would leave the others blocked inside RCCL: the root reports its own trouble IN the header (everyone then skips the
+// spectrum and fails), a rank whose engine does not match the header still receives the spectrum (into a scratch buffer of the
+// root's size) and fails afterwards.  Only a failure of RCCL itself cannot be made symmetric: abort the job then.
 int adsp_bcast_spectrum_rank(adsp_engine* e, const char* unique_id, int rank, int world, int root) {
     if (!e || !unique_id) return fail(ADSP_ERR_ARG, "NULL argument");
     if (world < 1 || rank < 0 || rank >= world || root < 0 || root >= world)
@@ -1006,35 +1013,52 @@ int adsp_bcast_spectrum_rank(adsp_engine* e, const char* unique_id, int rank, in
     if ((rc = bcast_buffer(e))) return rc;
     // header first: the root says what it sends, every rank checks it against its own engine (a rank that derived another
     // window layout must fail loudly instead of filtering with the wrong offsets)
-    float* d_hdr = e->d_spec;  // the spectrum buffer doubles as the 8-float header buffer
-    float hdr[8] = {0};
+    constexpr int kHdr = 12;
+    float* d_hdr = e->d_spec;  // the spectrum buffer doubles as the header buffer
+    float hdr[kHdr] = {0};
     bool is64 = false;
+    int root_trouble = 0;  // 1: no spectrum yet, 2: no host copy of it
     if (rank == root) {
-        if (!e->have_spectrum) return fail(ADSP_ERR_STATE, "the root engine has no spectrum yet (adsp_set_spectrum)");
+        if (!e->have_spectrum) root_trouble = 1;
         is64 = e->host_spec.empty();
-        if (is64 && e->host_spec64.empty()) return fail(ADSP_ERR_STATE, "internal: the root engine kept no copy of its spectrum");
-        const float h[8] = {(float)e->cfg.chunk_size, (float)e->cfg.fft_size, (float)e->cfg.history_chunks, (float)e->cfg.lookback,
-                            (float)e->cfg.out_offset, (float)e->cfg.sample_format, is64 ? 1.f : 0.f, (float)e->kernel_reach};
+        if (!root_trouble && is64 && e->host_spec64.empty()) root_trouble = 2;
+        const float h[kHdr] = {(float)e->cfg.chunk_size, (float)e->cfg.fft_size, (float)e->cfg.history_chunks, (float)e->cfg.lookback,
+                               (float)e->cfg.out_offset, (float)e->cfg.sample_format, is64 ? 1.f : 0.f, (float)e->kernel_reach, (float)root_trouble, 0.f, 0.f, 0.f};
         memcpy(hdr, h, sizeof hdr);
         HIP_TRY(hipMemcpyAsync(d_hdr, hdr, sizeof hdr, hipMemcpyHostToDevice, e->copy_stream));
         HIP_TRY(hipStreamSynchronize(e->copy_stream));  // (hdr is a stack array)
     }
-    if ((rc = adsp::rccl_broadcast_rank(unique_id, rank, world, root, e->cfg.device_id, d_hdr, 8, e->copy_stream))) return rc;
+    if ((rc = adsp::rccl_broadcast_rank(unique_id, rank, world, root, e->cfg.device_id, d_hdr, kHdr, e->copy_stream))) return rc;
     HIP_TRY(hipMemcpyAsync(hdr, d_hdr, sizeof hdr, hipMemcpyDeviceToHost, e->copy_stream));
     HIP_TRY(hipStreamSynchronize(e->copy_stream));
+    if ((int)hdr[8] != 0)  // every rank reads the same header: every rank leaves here, nobody enters the second collective
+        return fail(ADSP_ERR_STATE, (int)hdr[8] == 1 ? "rank %d (the root) has no spectrum yet (adsp_set_spectrum): nothing was broadcast"
+                                                     : "internal: rank %d (the root) kept no copy of its spectrum: nothing was broadcast", root);
     const adsp_config& c = e->cfg;
     const int mine[6] = {c.chunk_size, c.fft_size, c.history_chunks, c.lookback, c.out_offset, c.sample_format};
-    for (int i = 0; i < 6; ++i)
-        if ((int)hdr[i] != mine[i])
-            return fail(ADSP_ERR_ARG, "rank %d: engine geometry (chunk %d, fft %d, history %d, lookback %d, out_offset %d, format %d) differs from "
-                        "rank %d's (%d, %d, %d, %d, %d, %d)", rank, mine[0], mine[1], mine[2], mine[3], mine[4], mine[5], root, (int)hdr[0],
-                        (int)hdr[1], (int)hdr[2], (int)hdr[3], (int)hdr[4], (int)hdr[5]);
+    bool match = true;
+    for (int i = 0; i < 6; ++i) match = match && (int)hdr[i] == mine[i];
     is64 = hdr[6] != 0.f;
     const int reach = (int)hdr[7];
+    // what the root sends: 2 (F/2 + 1) floats of ITS transform length (twice as many for a float64 spectrum)
+    const size_t count = 2 * (size_t)((int)hdr[1] / 2 + 1) * (is64 ? 2 : 1);
+    if (!match) {
+        float* scratch = nullptr;
+        HIP_TRY(hipMalloc(&scratch, count * sizeof(float)));
+        rc = adsp::rccl_broadcast_rank(unique_id, rank, world, root, e->cfg.device_id, scratch, count, e->copy_stream);
+        (void)hipStreamSynchronize(e->copy_stream);
+        (void)hipFree(scratch);
+        if (rc) return rc;
+        return fail(ADSP_ERR_ARG, "rank %d: engine geometry (chunk %d, fft %d, history %d, lookback %d, out_offset %d, format %d) differs from "
+                    "rank %d's (%d, %d, %d, %d, %d, %d); the spectrum was received and dropped, this engine keeps its own filter", rank, mine[0], mine[1],
+                    mine[2], mine[3], mine[4], mine[5], root, (int)hdr[0], (int)hdr[1], (int)hdr[2], (int)hdr[3], (int)hdr[4], (int)hdr[5]);
+    }
     if (rank == root && (rc = bcast_stage_root(e, is64))) return rc;
-    if ((rc = adsp::rccl_broadcast_rank(unique_id, rank, world, root, e->cfg.device_id, e->d_spec, bcast_floats(e, is64), e->copy_stream))) return rc;
+    if ((rc = adsp::rccl_broadcast_rank(unique_id, rank, world, root, e->cfg.device_id, e->d_spec, count, e->copy_stream))) return rc;
     return bcast_adopt(e, is64, reach);
 }
+
+int adsp_rccl_finalize(void) { return adsp::rccl_finalize(); }
 
 int adsp_get_spectrum(const adsp_engine* e, float* spectrum, int n_bins) {
     if (!e || !spectrum) return fail(ADSP_ERR_ARG, "NULL argument");
@@ -1067,6 +1091,7 @@ int adsp_set_kernel_reach(adsp_engine* e, int taps_at_negative_indices) {
 
 int adsp_set_block_outputs(adsp_engine* e, int v) {
     if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    ADSP_NOT_LIVE(e);
     // generic kernel: whole register pairs; specialised kernels: quarter chunks (their store phase is a 4-way switch)
     const int T2 = e->generic ? 4 * e->plan->T : e->cfg.chunk_size / 4;
     if (v <= 0 || v % T2 || e->cfg.out_offset + v > e->cfg.fft_size)
@@ -1121,6 +1146,7 @@ int tremolo_run(adsp_engine* e, int max_steps, int* phase) {
 
 int adsp_set_epilogue(adsp_engine* e, int effect, float p0, float p1, float p2) {
     if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    ADSP_NOT_LIVE(e);
     if (effect < ADSP_EFFECT_NONE || effect > ADSP_EFFECT_BIT_CRUSHER) return fail(ADSP_ERR_ARG, "unknown effect %d", effect);
     if (effect != ADSP_EFFECT_NONE && e->cfg.sample_format != ADSP_FORMAT_F32)
         return fail(ADSP_ERR_ARG, "fused effects need a float32 engine");
@@ -1252,6 +1278,7 @@ int adsp_set_epilogue_state(adsp_engine* e, long long state) {
 
 int adsp_set_accumulate(adsp_engine* e, int mode) {
     if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    ADSP_NOT_LIVE(e);
     if (mode < 0 || mode > 2) return fail(ADSP_ERR_ARG, "accumulate mode must be 0, 1 or 2");
     if (mode && e->cfg.sample_format != ADSP_FORMAT_F32) return fail(ADSP_ERR_ARG, "accumulating output needs a float32 engine");
     if (mode == 2 || (mode == 1 && !e->generic)) {  // these run on the twin kernel
@@ -1556,6 +1583,7 @@ int adsp_ring_join(adsp_engine* e, void* stream_v) {
 // ---- resident ring launches -------------------------------------------------------------------------------------
 int adsp_ring_produce_begin(adsp_engine* e, void** d_slot, void* stream_v) {
     if (!e || !d_slot) return fail(ADSP_ERR_ARG, "NULL argument");
+    ADSP_NOT_LIVE(e);  // (the session owns the ring: resident_prepare would switch its mode, a launch would move ring_pos under adsp_live_slot)
     int rc = set_device(e);
     if (rc) return rc;
     if ((rc = resident_prepare(e))) return rc;
@@ -1579,6 +1607,7 @@ int adsp_ring_produce_begin(adsp_engine* e, void** d_slot, void* stream_v) {
 
 int adsp_ring_produce_end(adsp_engine* e, void* stream_v) {
     if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    ADSP_NOT_LIVE(e);
     if (!e->resident_mode || e->pub_pending < 1) return fail(ADSP_ERR_STATE, "adsp_ring_produce_end without adsp_ring_produce_begin");
     int rc = set_device(e);
     if (rc) return rc;
@@ -1613,6 +1642,7 @@ int adsp_ring_produce_end(adsp_engine* e, void* stream_v) {
 int adsp_apply_ring_resident(adsp_engine* e, void* d_out, int n_steps, void* stream_v) {
     if (!e || !d_out) return fail(ADSP_ERR_ARG, "NULL argument");
     if (!e->have_spectrum) return fail(ADSP_ERR_STATE, "adsp_set_spectrum has not been called");
+    ADSP_NOT_LIVE(e);
     int rc = set_device(e);
     if (rc) return rc;
     if ((rc = resident_prepare(e))) return rc;

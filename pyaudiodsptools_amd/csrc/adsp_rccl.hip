@@ -128,21 +128,52 @@ int rccl_unique_id(char* out) {
 
 // d_buf: `count` floats on device `dev` of THIS process (rank `rank` of `world`); stream-ordered on `stream`, every rank's
 // buffer then holds root's.  The first call with a given id builds the communicator (collective: every rank must call).
+// g_mu guards the tables only: ncclCommInitRank and the broadcast BLOCK until every rank has joined, and two ranks driven from
+// two threads of one process would otherwise wait for each other for ever (one inside the init, one for the lock).
 int rccl_broadcast_rank(const char* unique_id, int rank, int world, int root, int dev, float* d_buf, size_t count, hipStream_t stream) {
-    std::lock_guard<std::mutex> lock(g_mu);
-    int rc = load_api();
-    if (rc) return rc;
     std::string key(unique_id, ADSP_RCCL_UNIQUE_ID_BYTES);
     key += ":" + std::to_string(rank) + "/" + std::to_string(world) + "@" + std::to_string(dev);
-    auto it = g_rank_comms.find(key);
-    if (it == g_rank_comms.end()) {
+    comm_t comm = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        int rc = load_api();
+        if (rc) return rc;
+        auto it = g_rank_comms.find(key);
+        if (it != g_rank_comms.end()) comm = it->second;
+    }
+    if (!comm) {
         UniqueId id;
         memcpy(id.internal, unique_id, sizeof id.internal);
-        comm_t comm = nullptr;
-        NCCL_TRY(g_api.CommInitRank(&comm, world, id, rank));
-        it = g_rank_comms.emplace(key, comm).first;
+        NCCL_TRY(g_api.CommInitRank(&comm, world, id, rank));  // (g_api is immutable once loaded)
+        std::lock_guard<std::mutex> lock(g_mu);
+        auto ins = g_rank_comms.emplace(key, comm);
+        if (!ins.second) {  // another thread joined as the very same rank meanwhile (a caller error that RCCL let through): keep the first
+            (void)g_api.CommDestroy(comm);
+            comm = ins.first->second;
+        }
     }
-    NCCL_TRY(g_api.Broadcast(d_buf, d_buf, count, kNcclFloat32, root, it->second, stream));
+    NCCL_TRY(g_api.Broadcast(d_buf, d_buf, count, kNcclFloat32, root, comm, stream));
+    return ADSP_OK;
+}
+
+// Destroys every communicator this library has built (process exit, or before a job re-forms with new ids).  The caller
+// guarantees that no broadcast is in flight.
+int rccl_finalize() {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!g_api.handle) return ADSP_OK;
+    int bad = kNcclSuccess;
+    for (auto& kv : g_rank_comms) {
+        const int r = g_api.CommDestroy(kv.second);
+        if (r != kNcclSuccess) bad = r;
+    }
+    g_rank_comms.clear();
+    for (auto& kv : g_comms)
+        for (comm_t c : kv.second) {
+            const int r = g_api.CommDestroy(c);
+            if (r != kNcclSuccess) bad = r;
+        }
+    g_comms.clear();
+    if (bad != kNcclSuccess) return adsp::fail(ADSP_ERR_HIP, "ncclCommDestroy failed: %s", g_api.GetErrorString(bad));
     return ADSP_OK;
 }
 

@@ -57,24 +57,24 @@ namespace f64 {
 #ifndef ADSP_PLAN_3072
 #define ADSP_PLAN_3072 Plan<3072, 48, 3, 16, 16, 12, 1, false, true, 2>
 #endif
-#define ADSP_PLAN_LIST(S16, EPI)                                                    \
-    make_plan<Plan<64, 16, 2, 8, 8, 1, 1>, 16, 8, S16, EPI>(),                        \
-    make_plan<Plan<128, 16, 2, 16, 8, 1, 1>, 8, 8, S16, EPI>(),                       \
-    make_plan<Plan<128, 16, 2, 16, 8, 1, 1>, 8, 16, S16, EPI>(),                       \
-    make_plan<Plan<256, 16, 3, 4, 8, 8, 1>, 4, 8, S16, EPI>(),                        \
-    make_plan<Plan<256, 16, 3, 4, 8, 8, 1>, 4, 16, S16, EPI>(),                        \
-    make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 2, 8, S16, EPI>(),                       \
-    make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 2, 16, S16, EPI>(),                       \
-    make_plan<Plan<1024, 16, 3, 16, 8, 8, 1>, 1, 8, S16, EPI>(),                      \
-    make_plan<Plan<1024, 16, 3, 16, 8, 8, 1>, 1, 16, S16, EPI>(),                      \
-    make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 8, S16, EPI>(),                     \
-    make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 16, S16, EPI>(),                     \
-    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 8, S16, EPI>(),              \
-    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 16, S16, EPI>(),              \
-    make_plan<ADSP_PLAN_8192, 1, 8, S16, EPI>(),                                      \
-    make_plan<ADSP_PLAN_8192, 1, 16, S16, EPI>(),                                      \
-    make_plan<ADSP_PLAN_16384, 1, 16, S16, EPI>(),                                    \
-    make_plan<ADSP_PLAN_3072, 1, 6, S16, EPI>()
+#define ADSP_PLAN_LIST(S16, EPI, U4)                                                   \
+    make_plan<Plan<64, 16, 2, 8, 8, 1, 1>, 16, 8, S16, EPI, U4>(),                        \
+    make_plan<Plan<128, 16, 2, 16, 8, 1, 1>, 8, 8, S16, EPI, U4>(),                       \
+    make_plan<Plan<128, 16, 2, 16, 8, 1, 1>, 8, 16, S16, EPI, U4>(),                       \
+    make_plan<Plan<256, 16, 3, 4, 8, 8, 1>, 4, 8, S16, EPI, U4>(),                        \
+    make_plan<Plan<256, 16, 3, 4, 8, 8, 1>, 4, 16, S16, EPI, U4>(),                        \
+    make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 2, 8, S16, EPI, U4>(),                       \
+    make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 2, 16, S16, EPI, U4>(),                       \
+    make_plan<Plan<1024, 16, 3, 16, 8, 8, 1>, 1, 8, S16, EPI, U4>(),                      \
+    make_plan<Plan<1024, 16, 3, 16, 8, 8, 1>, 1, 16, S16, EPI, U4>(),                      \
+    make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 8, S16, EPI, U4>(),                     \
+    make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 16, S16, EPI, U4>(),                     \
+    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 8, S16, EPI, U4>(),              \
+    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 16, S16, EPI, U4>(),              \
+    make_plan<ADSP_PLAN_8192, 1, 8, S16, EPI, U4>(),                                      \
+    make_plan<ADSP_PLAN_8192, 1, 16, S16, EPI, U4>(),                                      \
+    make_plan<ADSP_PLAN_16384, 1, 16, S16, EPI, U4>(),                                    \
+    make_plan<ADSP_PLAN_3072, 1, 6, S16, EPI, U4>()
 
 // tables live in plans_f32.hip / plans_s16.hip (internal linkage there: host-only data, the device pass only
 // needs to see the instantiations)

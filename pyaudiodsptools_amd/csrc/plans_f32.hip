@@ -1,10 +1,10 @@
 // plans_f32.hip - kernel instantiations for float32 samples
-#define ADSP_PLANS_WITH_UNALIGNED 1  // this table also carries the dword-access kernels for chunk sizes that are not multiples of 4
+// (this table also carries the dword-access kernels for chunk sizes that are not multiples of 4: the third argument of ADSP_PLAN_LIST)
 #include "plan_table.hpp"
 
 namespace {
 using namespace adsp;
-const PlanInfo kPlans[] = {ADSP_PLAN_LIST(false, false)};
+const PlanInfo kPlans[] = {ADSP_PLAN_LIST(false, false, true)};
 }  // namespace
 
 const adsp::PlanInfo* adsp::plans_f32(int* count) {

@@ -3,7 +3,7 @@
 
 namespace {
 using namespace adsp;
-const PlanInfo kPlans[] = {ADSP_PLAN_LIST(false, true)};
+const PlanInfo kPlans[] = {ADSP_PLAN_LIST(false, true, false)};
 }  // namespace
 
 const adsp::PlanInfo* adsp::plans_f32_epi(int* count) {

@@ -3,7 +3,7 @@
 
 namespace {
 using namespace adsp;
-const PlanInfo kPlans[] = {ADSP_PLAN_LIST(true, false)};
+const PlanInfo kPlans[] = {ADSP_PLAN_LIST(true, false, false)};
 }  // namespace
 
 const adsp::PlanInfo* adsp::plans_s16(int* count) {

@@ -6,7 +6,7 @@
 namespace adsp {
 namespace f64 {
 namespace {
-const PlanInfo kPlans[] = {ADSP_PLAN_LIST(true, false)};
+const PlanInfo kPlans[] = {ADSP_PLAN_LIST(true, false, false)};
 }  // namespace
 }  // namespace f64
 }  // namespace adsp

@@ -43,6 +43,7 @@ class _FFTDevice:
         self.float32_array_input_1 = zeros
         self.float32_array_input_2 = zeros
         self.float32_array_input_3 = zeros
+        self._last_output = None
 
     def _rotate(self, x):
         self.float32_array_input_3 = self.float32_array_input_2
@@ -60,6 +61,7 @@ class _FFTDevice:
         x = np.ascontiguousarray(flat, dtype=np.float32)
         y = self.engine.apply_host(x.reshape(1, self._n))
         self._rotate(float32_array_input)
+        self._last_output = y.reshape(self._n)
         return y.reshape(self._n)
 
     def apply_batch(self, chunk_batch):
@@ -67,12 +69,26 @@ class _FFTDevice:
         x = np.asarray(chunk_batch)
         y = self.engine.apply_host(x)
         self._rotate(x if x.ndim == 2 else x[-1])
+        self._last_output = y if y.ndim == 2 else y[-1]
         return y
 
     def reset(self):
         self.engine.reset()
         zeros = np.zeros(self._n) if self.channels == 1 else np.zeros((self.channels, self._n))
         self.float32_array_input_1 = self.float32_array_input_2 = self.float32_array_input_3 = zeros
+        self._last_output = None
+
+    def _concatenated_inputs(self):
+        """The 3N-sample buffer the reference transforms: chunks k-2, k-1, k flattened (EffectFFTFilter.py:67-68)."""
+        return np.concatenate((self.float32_array_input_3, self.float32_array_input_2, self.float32_array_input_1), axis=None)
+
+    def _cut_filter_filtered_signal(self):
+        # EffectFFTFilter.py:39 (zeros(3N) until the first apply), :67-73 (afterwards the sliced inverse transform: N complex values
+        # whose real part, cast to float32, is what apply returned).  Read-only here: the arithmetic happened on the GPU, the imaginary
+        # part - rounding noise of the reference's complex transform - is exactly zero.
+        if self._last_output is None:
+            return np.zeros(self._n * 3)
+        return np.asarray(self._last_output).astype(np.complex128)
 
 
 class CreateHighCutFilter(_FFTDevice):
@@ -90,6 +106,11 @@ class CreateHighCutFilter(_FFTDevice):
         """3N-point complex128 spectrum, as the reference exposes it (EffectFFTFilter.py:45-47)."""
         return reference_spectrum_3n(self.fir.taps, self._n)
 
+    @property
+    def filtered_signal(self):
+        """The reference's inspectable work buffer (EffectFFTFilter.py:39, :67-73), read-only."""
+        return self._cut_filter_filtered_signal()
+
 
 class CreateLowCutFilter(_FFTDevice):
     """FFT low-cut (high-pass) device.  cutoff_frequency defaults to 160 (EffectFFTFilter.py:91)."""
@@ -103,6 +124,11 @@ class CreateLowCutFilter(_FFTDevice):
     @property
     def sinc_filter(self):
         return reference_spectrum_3n(self.fir.taps, self._n)
+
+    @property
+    def filtered_signal(self):
+        """The reference's inspectable work buffer (EffectFFTFilter.py:115, :143-149), read-only."""
+        return self._cut_filter_filtered_signal()
 
 
 class CreateEQ3BandFFT(_FFTDevice):
@@ -122,6 +148,16 @@ class CreateEQ3BandFFT(_FFTDevice):
         taps = eq3_composite(lowshelf_frequency, lowshelf_db, midband_frequency, midband_db, highshelf_frequency,
                              highshelf_db, self.fS, config.chunk_size)
         self._setup(taps, channels, device)
+
+    @property
+    def filtered_signal(self):
+        """EffectEQ3BandFFT.py:147: zeros(3N) - the reference's apply works on locals and never touches it again."""
+        return np.zeros(self._n * 3)
+
+    @property
+    def original_signal(self):
+        """EffectEQ3BandFFT.py:148, :175-176: the three most recent chunks flattened (zeros(3N) before the first apply).  Read-only."""
+        return self._concatenated_inputs()
 
     @property
     def sinc_filter_highshelf(self):

@@ -46,48 +46,74 @@ def init_process_group(backend=None):
     return dist
 
 
-_job_unique_id = None
+_job_unique_ids = {}  # id file path -> the 128 bytes this process took part with (one communicator per id, cached by libadsp)
+_ID_MAGIC = b"ADSPRCCL1"
 
 
-def exchange_unique_id(rank, world, make_id, path=None, timeout=120.0):
-    """Hand the 128 bytes `make_id()` returns on rank 0 to every rank of a one-process-per-GPU job - once per process (the
-    communicator behind it is cached by libadsp and reused for every later broadcast).
-
-    The carrier is a file: `path`, or $ADSP_RCCL_ID_FILE, or <tmp>/adsp_rccl_<MASTER_PORT>_<parent pid> (ranks started by
-    one torchrun agent share the parent, so two jobs on one box never read each other's id; launchers without a common
-    parent set ADSP_RCCL_ID_FILE).  Rank 0 writes it atomically (temporary file + rename) and removes it at exit."""
-    global _job_unique_id
-    if _job_unique_id is not None:
-        return _job_unique_id
-    if world == 1:
-        _job_unique_id = make_id()
-        return _job_unique_id
+def _id_file_path(path=None):
+    """`path`, or $ADSP_RCCL_ID_FILE, or <tmp>/adsp_rccl_<MASTER_PORT>_<parent pid>_<run id>_<restart count>: ranks started by one
+    torchrun agent share the parent pid and the port; the elastic run id and restart count (TORCHELASTIC_RUN_ID /
+    TORCHELASTIC_RESTART_COUNT, set by torchrun) make every ATTEMPT of a job use a name of its own, so a restarted worker group never
+    polls the file of the attempt that died."""
     import tempfile
-    path = path or os.environ.get("ADSP_RCCL_ID_FILE") or os.path.join(
-        tempfile.gettempdir(), f"adsp_rccl_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
+    if path or os.environ.get("ADSP_RCCL_ID_FILE"):
+        return path or os.environ["ADSP_RCCL_ID_FILE"]
+    run = "".join(ch for ch in os.environ.get("TORCHELASTIC_RUN_ID", "none") if ch.isalnum() or ch in "-_")[:40]
+    return os.path.join(tempfile.gettempdir(), f"adsp_rccl_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{run}_"
+                                               f"{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}")
+
+
+def exchange_unique_id(rank, world, make_id, path=None, timeout=120.0, max_age=300.0):
+    """Hand the 128 bytes `make_id()` returns on rank 0 to every rank of a one-process-per-GPU job - once per process and id file
+    (the communicator behind it is cached by libadsp and reused for every later broadcast).
+
+    The carrier is a small file (_id_file_path) - NODE-LOCAL by default: a multi-node job points ADSP_RCCL_ID_FILE at shared storage
+    (or hands the id over any other way and calls FirEngine.bcast_rank itself).  Rank 0 removes whatever is left under that name,
+    then creates the file with O_EXCL and mode 0600 under a temporary name and renames it into place; it holds a magic word, rank
+    0's pid and start time, and the id.  The other ranks accept a file only if it is owned by their own user, carries the magic
+    word and is not older than `max_age` seconds (a file left behind by a killed job of long ago is ignored, not joined)."""
+    path = _id_file_path(path)
+    if path in _job_unique_ids:
+        return _job_unique_ids[path]
+    if world == 1:
+        _job_unique_ids[path] = bytes(make_id())
+        return _job_unique_ids[path]
     if rank == 0:
         uid = bytes(make_id())
+        try:
+            os.remove(path)  # a leftover of an attempt that was killed (atexit did not run): nobody may read it as this attempt's
+        except FileNotFoundError:
+            pass
         tmp = f"{path}.{os.getpid()}.tmp"
-        with open(tmp, "wb") as fh:
-            fh.write(uid)
+        try:
+            os.remove(tmp)
+        except FileNotFoundError:
+            pass
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "wb") as fh:
+            fh.write(_ID_MAGIC + f"{os.getpid():010d}{time.time():020.3f}".encode() + uid)
         os.replace(tmp, path)
         import atexit
         atexit.register(lambda: os.path.exists(path) and os.remove(path))
     else:
         t0 = time.time()
+        head = len(_ID_MAGIC) + 30
         while True:
             try:
+                st = os.stat(path)
                 with open(path, "rb") as fh:
-                    uid = fh.read()
-                if len(uid) >= 128:
-                    uid = uid[:128]
+                    blob = fh.read()
+                fresh = time.time() - st.st_mtime <= max_age
+                if st.st_uid == os.getuid() and fresh and blob.startswith(_ID_MAGIC) and len(blob) >= head + 128:
+                    uid = blob[head:head + 128]
                     break
             except FileNotFoundError:
                 pass
             if time.time() - t0 > timeout:
-                raise TimeoutError(f"rank {rank}: no RCCL id from rank 0 in {path} after {timeout:.0f} s")
+                raise TimeoutError(f"rank {rank}: no RCCL id from rank 0 in {path} after {timeout:.0f} s (the file is node-local: a "
+                                   "multi-node job sets ADSP_RCCL_ID_FILE to a path on shared storage)")
             time.sleep(0.01)
-    _job_unique_id = uid
+    _job_unique_ids[path] = uid
     return uid
 
 

@@ -322,6 +322,18 @@ class ClockProbe:
         self._res = ctypes.c_void_p(None)
         return mhz.value
 
+    def __del__(self):  # a probe nobody read: its pinned result buffer is freed by the read (which waits for the probe kernel)
+        try:
+            if getattr(self, "_res", None) is not None and self._res.value:
+                self.read()
+        except Exception:
+            pass
+
+
+def rccl_finalize():
+    """adsp_rccl_finalize: destroy every RCCL communicator libadsp has built (no broadcast may be in flight)."""
+    _capi.check(_capi.load().adsp_rccl_finalize())
+
 
 def rccl_version():
     v = ctypes.c_int(0)

@@ -185,7 +185,7 @@ def test_sharded_bank_abi_carrier_host_logic(monkeypatch):
     torch.distributed involved."""
     from pyaudiodsptools_amd import FirStream, design, dist
     import pyaudiodsptools_amd.engine as engine_mod
-    monkeypatch.setattr(dist, "_job_unique_id", None)
+    monkeypatch.setattr(dist, "_job_unique_ids", {})
     monkeypatch.setattr(engine_mod, "rccl_unique_id", lambda: b"\x07" * 128)
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.delenv("RANK", raising=False)
@@ -197,6 +197,41 @@ def test_sharded_bank_abi_carrier_host_logic(monkeypatch):
     assert np.array_equal(bank.spectrum, np.arange(4, dtype=np.float32))
     with pytest.raises(ValueError):
         dist.ShardedFirBank(fir, 10, engine_factory=_FakeAbiEngine, carrier="mpi")
+
+
+def test_unique_id_file_exchange_ignores_leftovers_and_is_keyed_by_path(tmp_path, monkeypatch):
+    """the id file carries a magic word, must belong to this user and must be fresh; rank 0 replaces whatever an earlier
+    (killed) attempt left under the name; the per-process cache is keyed by the file, and every elastic attempt has its own name."""
+    import os
+    import threading
+    import time as _time
+    from pyaudiodsptools_amd import dist
+    monkeypatch.setattr(dist, "_job_unique_ids", {})
+    path = str(tmp_path / "id")
+    open(path, "wb").write(b"\x01" * 200)  # a leftover without the magic word: never accepted
+    with pytest.raises(TimeoutError):
+        dist.exchange_unique_id(1, 2, None, path=path, timeout=0.3)
+    stale = str(tmp_path / "stale")
+    open(stale, "wb").write(dist._ID_MAGIC + b"0" * 30 + b"\x02" * 128)
+    os.utime(stale, (_time.time() - 4000, _time.time() - 4000))  # well formed, but from a job of long ago
+    with pytest.raises(TimeoutError):
+        dist.exchange_unique_id(1, 2, None, path=stale, timeout=0.3)
+    got = {}
+    reader = threading.Thread(target=lambda: got.setdefault("uid", dist.exchange_unique_id(1, 2, None, path=path, timeout=20.0)))
+    reader.start()
+    _time.sleep(0.2)
+    monkeypatch.setattr(dist, "_job_unique_ids", {})  # (rank 0 is another process in real life: its own cache)
+    uid0 = dist.exchange_unique_id(0, 2, lambda: b"\x07" * 128, path=path)
+    reader.join(20.0)
+    assert uid0 == b"\x07" * 128 and got["uid"] == uid0
+    assert (os.stat(path).st_mode & 0o777) == 0o600
+    assert dist.exchange_unique_id(0, 2, lambda: b"\x09" * 128, path=path) == uid0          # cached per path ...
+    assert dist.exchange_unique_id(0, 1, lambda: b"\x09" * 128, path=path + "b") == b"\x09" * 128  # ... another path, another id
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job/7")
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "0")
+    a = dist._id_file_path()
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "1")
+    assert dist._id_file_path() != a and "job7" in a
 
 
 def test_local_bank_float64_engines_keep_their_filter_through_the_broadcast():
