@@ -493,6 +493,43 @@ ADSP_API int adsp_exact_apply_device(adsp_exact* fir, const void* d_in, void* d_
 ADSP_API int adsp_exact_apply_host(adsp_exact* fir, const void* in, void* out, int n_steps);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Uniformly partitioned engines (round 5): streaming FIRs LONGER than one transform - the reference's own GPU example runs
+ * chunk_size 88200 (Example4.py:5, ModuleTestsGPU.py:35: CreateLowCutFilter -> 44 099 taps, CreateEQ3BandFFT -> 88 197).
+ *     out[tau] = y[tau - delay],   y = taps (*) s   (zero history),   taps cut into P partitions of B = adsp_upols_block_size() taps
+ * Every input block of B samples is transformed ONCE (2B-point real FFT), its spectrum kept in a frequency-domain delay line in HBM;
+ * an output block is ONE inverse transform of sum_p X_{b-p} H_p.  Two launches per call (forward transforms; multiply-accumulate +
+ * inverse + store), each over every (channel, block) at once - instead of one full engine pass per kernel slice.
+ *   spectra : [n_partitions][B + 1] interleaved (re, im) float32 = rfft(partition p of the taps zero-padded to 2B), computed by the
+ *             host in float64.  int16 engines: the host folds 32767/32768 into the taps (like ADSP_FORMAT_S16 engines).
+ *   delay   : multiple of 4, >= B (a reference device: chunk_size - look-ahead, rounded down to a multiple of 4 by delaying the
+ *             kernel by 0..3 taps).  chunk_size: multiple of 4, >= 16.  Batches: [step][channel][sample] like everything else.
+ *   max_steps: chunks one pair of launches covers at most (longer calls are split); sizes the delay line:
+ *             (ceil((max_steps * chunk_size + delay) / B) + n_partitions + 3) blocks of 8 B bytes per channel.
+ * A stateless fused effect (ADSP_EFFECT_* except the tremolo; float32 engines) is applied to the output registers.
+ * Calls of one engine must be ordered on one stream (or synchronised in between): the second launch reads what the first wrote.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct adsp_upols adsp_upols; /* opaque */
+typedef struct adsp_upols_config {
+    int device_id;
+    int chunk_size;
+    int n_channels;
+    int block_size;     /* must equal adsp_upols_block_size() */
+    int n_partitions;
+    int delay;
+    int sample_format;  /* ADSP_FORMAT_F32 or ADSP_FORMAT_S16 */
+    int max_steps;
+} adsp_upols_config;
+ADSP_API int adsp_upols_block_size(void);
+ADSP_API int adsp_upols_create(const adsp_upols_config* cfg, const float* spectra, adsp_upols** out);
+ADSP_API void adsp_upols_destroy(adsp_upols* fir);
+ADSP_API int adsp_upols_reset(adsp_upols* fir); /* history and delay line back to zeros */
+ADSP_API int adsp_upols_set_epilogue(adsp_upols* fir, int effect, float p0, float p1, float p2);
+ADSP_API int adsp_upols_info(const adsp_upols* fir, int* history_chunks, int* delay_line_blocks, size_t* delay_line_bytes);
+/* d_in / d_out: device [n_steps][n_channels][chunk_size], NOT aliased; asynchronous on `stream` */
+ADSP_API int adsp_upols_apply_device(adsp_upols* fir, const void* d_in, void* d_out, int n_steps, void* stream);
+ADSP_API int adsp_upols_apply_host(adsp_upols* fir, const void* in, void* out, int n_steps);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Counter-based synthetic input: sample (channel c, absolute index t) is a pure function of (seed, c, t) -
  * uniform(-1, 1) float32 (2^24 equidistant values, scaled by `amplitude`) or uniform int16 in [-16384, 16384) - written on the
  * device straight into a [n_steps][n_channels][chunk_size] batch whose first sample of channel j is absolute index first_sample

@@ -17,13 +17,13 @@ from .effects import (CreateHardDistortion, CreateSaturator, CreateSoftClipper, 
                       Effect, MixSignals, VolumeChange)
 from .delay import CreateDelay, DelayLine
 from .recursive import CreateCompressor, CreateEQ3Band, CreateGate, ScanEngine
-from .engine import ExactFirEngine, FirEngine, MixBus, PartitionedFirEngine, make_engine
+from .engine import ExactFirEngine, FirEngine, MixBus, PartitionedFirEngine, UpolsFirEngine, make_engine
 from . import wavio as Utility
 from .wavio import (CombineChunks, MakeChunks, MonoWavToNumpy16BitInt, MonoWavToNumpyFloat, NumpyFloatToWav,
                     StereoWavToNumpyFloat, WavBank)
 
 __all__ = ["config", "CreateHighCutFilter", "CreateLowCutFilter", "CreateEQ3BandFFT", "CreateHighCutFilterGPU",
-           "CreateLowCutFilterGPU", "CreateEQ3BandFFTGPU", "FirEngine", "ExactFirEngine", "PartitionedFirEngine", "make_engine", "FirStream", "fuse", "Utility", "MakeChunks",
+           "CreateLowCutFilterGPU", "CreateEQ3BandFFTGPU", "FirEngine", "ExactFirEngine", "PartitionedFirEngine", "UpolsFirEngine", "make_engine", "FirStream", "fuse", "Utility", "MakeChunks",
            "CombineChunks", "MonoWavToNumpyFloat", "MonoWavToNumpy16BitInt", "StereoWavToNumpyFloat", "NumpyFloatToWav",
            "WavBank", "CreateSoftClipper", "CreateHardDistortion", "CreateSaturator", "VolumeChange", "CreateVolumeChange",
            "Effect", "CreateTremolo", "MixSignals", "MixBus", "CreateDelay", "DelayLine", "CreateEQ3Band", "CreateCompressor", "CreateGate", "ScanEngine"]

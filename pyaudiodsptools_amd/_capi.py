@@ -50,6 +50,11 @@ class AdspExactConfig(ctypes.Structure):
                 ("n_taps", ctypes.c_int), ("delay", ctypes.c_int), ("sample_format", ctypes.c_int)]
 
 
+class AdspUpolsConfig(ctypes.Structure):
+    _fields_ = [("device_id", ctypes.c_int), ("chunk_size", ctypes.c_int), ("n_channels", ctypes.c_int), ("block_size", ctypes.c_int),
+                ("n_partitions", ctypes.c_int), ("delay", ctypes.c_int), ("sample_format", ctypes.c_int), ("max_steps", ctypes.c_int)]
+
+
 _c_int_p = ctypes.POINTER(ctypes.c_int)
 _c_float_p = ctypes.POINTER(ctypes.c_float)
 _engine_p = ctypes.c_void_p
@@ -104,6 +109,14 @@ SIGNATURES = {
     "adsp_exact_reset": (ctypes.c_int, [ctypes.c_void_p]),
     "adsp_exact_apply_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "adsp_exact_apply_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    "adsp_upols_block_size": (ctypes.c_int, []),
+    "adsp_upols_create": (ctypes.c_int, [ctypes.POINTER(AdspUpolsConfig), ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "adsp_upols_destroy": (None, [ctypes.c_void_p]),
+    "adsp_upols_reset": (ctypes.c_int, [ctypes.c_void_p]),
+    "adsp_upols_set_epilogue": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float]),
+    "adsp_upols_info": (ctypes.c_int, [ctypes.c_void_p, _c_int_p, _c_int_p, ctypes.POINTER(ctypes.c_size_t)]),
+    "adsp_upols_apply_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "adsp_upols_apply_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "adsp_reset": (ctypes.c_int, [_engine_p]),
     "adsp_apply_host": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "adsp_apply_device": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),

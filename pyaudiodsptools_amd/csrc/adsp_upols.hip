@@ -1,0 +1,556 @@
+// adsp_upols.hip - uniformly partitioned overlap-save: streaming FIRs LONGER than one transform (round 5).
+//
+// The reference's own GPU example runs chunk_size 88200 (Example4.py:5, ModuleTestsGPU.py:35): a low cut of 44 099 taps, an EQ
+// composite of 88 197 - more than the largest transform of fftconv_kernel.hpp (32768 real points) can take in one piece.  Round 1-4
+// cut such a kernel into slices of <= 14336 taps and ran ONE ENGINE PER SLICE over the same input (PartitionedFirEngine: P forward
+// and P inverse transforms per block, P reads of the input, P - 1 read-modify-writes of the output).  Here the kernel is cut into P
+// partitions of B taps each (B = 8192: the M = 8192 plan, the fastest per point), every input block of B samples is transformed ONCE,
+// its spectrum kept in a frequency-domain delay line in HBM, and an output block is
+//
+//     y_b = irfft( sum_p  X_{b-p} . H_p )[B .. 2B)          X_b = rfft( s[(b-1)B .. (b+1)B) )
+//
+// - one forward transform, P spectrum multiply-accumulates, ONE inverse transform and one store per B samples.  Two launches per
+// call, each over every (channel, block) at once:
+//   upols_forward_kernel : window of 2B samples (generic chunk geometry: any chunk size divisible by 4) -> the plan's forward passes
+//                          -> the thread's registers, as they are, to the delay line.  What is stored is Z = FFT of the packed
+//                          sequence z[n] = x[2n] + i x[2n+1] in the REGISTER LAYOUT of the plan (element e = tid + T m of the
+//                          last forward pass), 8 M bytes per block: the real-FFT split, the product with H_p and the re-packing
+//                          for the inverse are ONE 2x2 complex matrix per bin pair (fftconv_core.inc: pair_op), linear in
+//                          (Z[k], conj Z[M-k]), so the sum over partitions can be taken on the unsplit Z - and both partners of
+//                          a pair live in the same thread, in the delay line exactly as in the registers.
+//   upols_mac_kernel     : acc += pair_op_p(Z_{b-p}) for p = 0 .. P-1 (the pair tables of H_p are built like an ordinary engine's),
+//                          the inverse passes, the kept half [B, 2B) converted / passed through a fused effect and stored.
+// The second launch reads what the first one wrote: the kernel boundary is the only synchronisation (no flags, no scopes).
+// Consecutive blocks of a channel share P - 1 spectra; blockIdx -> (channel, block) keeps them on one XCD (their L2).
+//
+// Time axis.  The stream is out[tau] = y[tau - delay], y = taps (*) s; blocks tile the y axis from absolute index 0, the chunk grid
+// is independent of them (chunk 88200 = 10.77 blocks).  A call for chunks k .. k+n-1 (input complete up to (k+n) N - 1) transforms
+// the blocks whose windows have just become complete and produces the output blocks that meet tau in [kN, (k+n)N); a block that
+// straddles a call boundary is multiplied and inverse-transformed in both calls (its forward transform once).  delay >= B keeps
+// every block an output needs inside the input that has arrived (the reference's devices delay by ~3/4 chunk).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "../../include/adsp.h"
+#include "capi_common.hpp"
+#include "plan_table.hpp"
+#include "table_build.hpp"
+
+using adsp::fail;
+
+namespace adsp {
+
+struct UpolsArgs {
+    const void* ring;    // [ring_slots][C][N] input history ring (samples of the engine's format)
+    const void* in;      // [n_steps][C][N]
+    void* out;           // [n_steps][C][N]
+    const void* zeros;   // N zero samples
+    const float4* tw;    // pass twiddles of the plan
+    const float4* pair;  // [P] pair tables (complex form), pair_stride float4 each
+    const float2* pair0; // [P] tables of thread 0's self-paired butterflies, pair0_stride float2 each
+    float2* zline;       // [C][R][PTS][T] float2: the delay line of forward-transformed blocks
+    int ring_pos, ring_slots, C, N, nh, n_steps;
+    float inv_n;
+    int P;               // partitions
+    int R;               // delay-line slots per channel
+    int slot_first;      // slot of the launch's first block
+    int nblk;            // blocks in this launch
+    int rel_first;       // forward: window start of the first block; mac: output time of the first block's first kept sample - relative to
+                         // the first new input sample of the call (may be negative)
+    int ncg;
+    int pair_stride, pair0_stride;
+    int epi_op;
+    float epi_p0, epi_p1, epi_p2;
+};
+
+namespace {
+
+template <class PL>
+__device__ __forceinline__ void upols_indices(int tid, int& ja, int& jb) {
+    static_assert(!PL::XL && PL::NBL == 2, "partitioned engines run the in-register pairing plans with two paired butterflies per thread");
+    ja = tid;
+    jb = (tid == 0) ? PL::NBL * PL::T / 2 : PL::NBL * PL::T - tid;
+}
+
+template <class PL>
+__device__ __forceinline__ bool upols_block(const UpolsArgs& a, int& c, int& blk) {
+    const int lin = static_cast<int>(blockIdx.x);
+    const int xcd = lin & 7;
+    const int idx = lin >> 3;
+    const int cgl = idx / a.nblk;
+    blk = idx - cgl * a.nblk;
+    c = cgl * 8 + xcd;  // one channel per workgroup; a channel's consecutive blocks stay on one XCD
+    return c < a.C;
+}
+
+}  // namespace
+
+// ---- launch 1: window -> forward passes -> delay line ----------------------------------------------------------------
+template <class PL, bool S16>
+__global__ __launch_bounds__(PL::T, 3) void upols_forward_kernel(const UpolsArgs a) {
+    constexpr int P = PL::P, T = PL::T;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    real2* lds = reinterpret_cast<real2*>(smem_raw);
+    const int tid = static_cast<int>(threadIdx.x);
+    int c, blk;
+    if (!upols_block<PL>(a, c, blk)) return;
+
+    using U = typename std::conditional<S16, unsigned, float>::type;  // storage unit: float, or a dword of two int16
+    constexpr int SPU = S16 ? 2 : 1;
+    const int N = a.N;
+    const size_t plane = static_cast<size_t>(a.C) * N / SPU;
+    const size_t chan_units = static_cast<size_t>(c) * N / SPU;
+    const bool odd = tid & 1;
+    const int t0 = a.rel_first + blk * PL::M + a.nh * N;  // window start on the biased (>= 0) time axis: history chunk -nh is chunk 0
+
+    real xr[P], xi[P];
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    typename std::conditional<S16, v2u, v4f>::type raw[P / 2];
+#pragma unroll
+    for (int u = 0; u < P / 2; ++u) {
+        // even lane: elements (tid, tid+1) of register 2u; odd lane: elements (tid-1, tid) of register 2u+1 (fftconv_core.inc)
+        const int elem = (tid - (odd ? 1 : 0)) + T * (2 * u + (odd ? 1 : 0));
+        int q, r;
+        locate_chunk(t0 + 2 * elem, N, a.inv_n, q, r);
+        q -= a.nh;
+        const U* base = static_cast<const U*>(a.zeros);
+        size_t off = r / SPU;
+        if (q < a.n_steps) {
+            if (q < 0) {
+                int slot = a.ring_pos + 1 + q;
+                slot += (slot < 0) ? a.ring_slots : 0;
+                slot = slot < 0 ? 0 : slot;
+                base = static_cast<const U*>(a.ring) + static_cast<size_t>(slot) * plane;
+            } else {
+                base = static_cast<const U*>(a.in) + static_cast<size_t>(q) * plane;
+            }
+            off += chan_units;
+        }
+        if constexpr (S16) raw[u] = *reinterpret_cast<const v2u*>(base + off);
+        else raw[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(base + off));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < P / 2; ++u) {
+        if constexpr (S16) {
+            const v2u v = raw[u];
+            const unsigned sx = lane_xor1_u(odd ? v.x : v.y);
+            unpack_s16(odd ? sx : v.x, xr[2 * u], xi[2 * u]);
+            unpack_s16(odd ? v.y : sx, xr[2 * u + 1], xi[2 * u + 1]);
+        } else {
+            const v4f v = raw[u];
+            const float sx = lane_xor1(odd ? v.x : v.z), sy = lane_xor1(odd ? v.y : v.w);
+            xr[2 * u] = odd ? sx : v.x;
+            xi[2 * u] = odd ? sy : v.y;
+            xr[2 * u + 1] = odd ? v.z : sx;
+            xi[2 * u + 1] = odd ? v.w : sy;
+        }
+    }
+    int ja, jb;
+    upols_indices<PL>(tid, ja, jb);
+    run_passes<PL, false, 0, const real4* __restrict__>(xr, xi, lds, a.tw, tid, ja, jb);
+
+    int slot = a.slot_first + blk;
+    slot -= slot >= a.R ? a.R : 0;
+    float2* z = a.zline + (static_cast<size_t>(c) * a.R + slot) * (static_cast<size_t>(P) * T) + tid;
+#pragma unroll
+    for (int m = 0; m < P; ++m) z[static_cast<size_t>(m) * T] = make_float2(xr[m], xi[m]);  // read back by the next launch (L2)
+}
+
+// ---- launch 2: sum over partitions of pair_op_p(Z_{b-p}) -> inverse passes -> kept half ----------------------------------
+template <class PL, bool S16>
+__global__ __launch_bounds__(PL::T, 3) void upols_mac_kernel(const UpolsArgs a) {
+    constexpr int P = PL::P, T = PL::T, R = PL::RL, NB = PL::NBL;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    real2* lds = reinterpret_cast<real2*>(smem_raw);
+    const int tid = static_cast<int>(threadIdx.x);
+    int c, blk;
+    if (!upols_block<PL>(a, c, blk)) return;
+
+    real ar[P], ai[P];
+#pragma unroll
+    for (int m = 0; m < P; ++m) ar[m] = ai[m] = 0.f;
+    const float2* zc = a.zline + static_cast<size_t>(c) * a.R * (static_cast<size_t>(P) * T) + tid;
+    for (int p = 0; p < a.P; ++p) {
+        int slot = a.slot_first + blk - p;
+        slot += slot < 0 ? a.R : 0;
+        slot -= slot >= a.R ? a.R : 0;
+        const float2* z = zc + static_cast<size_t>(slot) * (static_cast<size_t>(P) * T);
+        const float4* tab = a.pair + static_cast<size_t>(p) * a.pair_stride;
+        const float2* tab0 = a.pair0 + static_cast<size_t>(p) * a.pair0_stride;
+        auto accumulate = [&](int ia, int ib, const float2 c1, const float2 c2, const float2 c4) {
+            const float2 va = z[static_cast<size_t>(ia) * T];
+            float zar = va.x, zai = va.y, zbr, zbi;
+            if (ia == ib) {  // a bin that pairs with itself (k = 0 and k = M/2 of thread 0)
+                zbr = zar;
+                zbi = zai;
+            } else {
+                const float2 vb = z[static_cast<size_t>(ib) * T];
+                zbr = vb.x;
+                zbi = vb.y;
+            }
+            pair_op(zar, zai, zbr, zbi, c1, c2, c4);
+            ar[ia] += zar;
+            ai[ia] += zai;
+            if (ia != ib) {
+                ar[ib] += zbr;
+                ai[ib] += zbi;
+            }
+        };
+        // two sequential ifs, not if / else (register liveness over the linearised control flow: fftconv_core.inc, spectrum_stage)
+        if (tid != 0) {
+#pragma unroll
+            for (int h = 0; h < R / 2; ++h) {
+                const float4 f0 = tab[(h * 3 + 0) * T + tid];
+                const float4 f1 = tab[(h * 3 + 1) * T + tid];
+                const float4 f2 = tab[(h * 3 + 2) * T + tid];
+                const int r0 = 2 * h, r1 = 2 * h + 1;
+                accumulate(NB * r0, NB * (R - 1 - r0) + 1, make_float2(f0.x, f0.y), make_float2(f0.z, f0.w), make_float2(f1.x, f1.y));
+                accumulate(NB * r1, NB * (R - 1 - r1) + 1, make_float2(f1.z, f1.w), make_float2(f2.x, f2.y), make_float2(f2.z, f2.w));
+            }
+        }
+        if (tid == 0) {
+            // thread 0: the self-paired butterflies j = 0 (registers NB r) and j = M/R/2 (NB r + 1); entries as in spectrum_stage
+            accumulate(0, 0, tab0[0], tab0[1], tab0[2]);
+            accumulate(NB * (R / 2), NB * (R / 2), tab0[3], tab0[4], tab0[5]);
+#pragma unroll
+            for (int r = 1; r < R / 2; ++r) {
+                const int e = 2 + (r - 1);
+                accumulate(NB * r, NB * (R - r), tab0[e * 3], tab0[e * 3 + 1], tab0[e * 3 + 2]);
+            }
+#pragma unroll
+            for (int r = 0; r < R / 2; ++r) {
+                const int e = 2 + (R / 2 - 1) + r;
+                accumulate(NB * r + 1, NB * (R - 1 - r) + 1, tab0[e * 3], tab0[e * 3 + 1], tab0[e * 3 + 2]);
+            }
+        }
+    }
+    int ja, jb;
+    upols_indices<PL>(tid, ja, jb);
+    run_passes<PL, true, 0, const real4* __restrict__>(ai, ar, lds, a.tw, tid, ja, jb);  // inverse = forward on swapped parts
+
+    if (a.epi_op != 0) {  // wave-uniform: a stateless effect on the kept half (Saturator, SoftClipper, HardDistortion, Volume, BitCrusher)
+#pragma unroll
+        for (int m = P / 2; m < P; ++m) {
+            ar[m] = epilogue_value(ar[m], a.epi_op, a.epi_p0, a.epi_p1, a.epi_p2);
+            ai[m] = epilogue_value(ai[m], a.epi_op, a.epi_p0, a.epi_p1, a.epi_p2);
+        }
+    }
+
+    // kept: circular indices [B, 2B) = elements >= M/2 = registers m >= P/2; register m holds output time o + 2 (tid + T m) - B
+    using U = typename std::conditional<S16, unsigned, float>::type;
+    constexpr int SPU = S16 ? 2 : 1;
+    const int N = a.N;
+    const size_t plane = static_cast<size_t>(a.C) * N / SPU;
+    const size_t chan_units = static_cast<size_t>(c) * N / SPU;
+    const bool odd = tid & 1;
+    const int total = a.n_steps * N;
+    const int o = a.rel_first + blk * PL::M - PL::M;  // output time of circular index 0 of this block
+#pragma unroll
+    for (int u = P / 4; u < P / 2; ++u) {
+        const int elem = (tid - (odd ? 1 : 0)) + T * (2 * u + (odd ? 1 : 0));
+        const int tau = o + 2 * elem;
+        float sx, sy;
+        unsigned w0 = 0, w1 = 0, swx = 0;
+        if constexpr (S16) {
+            w0 = pack_s16(ar[2 * u], ai[2 * u]);
+            w1 = pack_s16(ar[2 * u + 1], ai[2 * u + 1]);
+            swx = lane_xor1_u(odd ? w0 : w1);
+        } else {
+            sx = lane_xor1(odd ? ar[2 * u] : ar[2 * u + 1]);
+            sy = lane_xor1(odd ? ai[2 * u] : ai[2 * u + 1]);
+        }
+        if (tau >= 0 && tau < total) {  // (the ends of a call cut a block: multiples of 4 samples on both sides)
+            int k, r;
+            locate_chunk(tau, N, a.inv_n, k, r);
+            U* dst = static_cast<U*>(a.out) + static_cast<size_t>(k) * plane + chan_units + r / SPU;
+            if constexpr (S16) {
+                typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                const v2u v = odd ? v2u{swx, w1} : v2u{w0, swx};
+                __builtin_nontemporal_store(v, reinterpret_cast<v2u*>(dst));
+            } else {
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f v = odd ? v4f{sx, sy, ar[2 * u + 1], ai[2 * u + 1]} : v4f{ar[2 * u], ai[2 * u], sx, sy};
+                __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(dst));
+            }
+        }
+    }
+}
+
+}  // namespace adsp
+
+// ------------------------------------------------------------------------------------------------------------------------------
+namespace {
+using namespace adsp;
+using namespace adsp::tables;
+using UPL = ADSP_PLAN_8192;  // B = 8192: 32 points per thread, 256 threads, half-buffer exchanges (32 KiB of LDS)
+constexpr int kB = UPL::M;
+
+constexpr PlanInfo upols_plan_shape() {
+    return PlanInfo{UPL::M, 8, UPL::P, UPL::T, 1, UPL::NP, UPL::XL ? 1 : 0, {UPL::fwd(0), UPL::fwd(1), UPL::fwd(2), UPL::fwd(3)},
+                    UPL::tw_total, UPL::LDS_ELEMS * (int)sizeof(float2), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+}
+constexpr int kLds = UPL::LDS_ELEMS * (int)sizeof(float2);
+}  // namespace
+
+struct adsp_upols {
+    adsp_upols_config cfg;
+    int nh, ring_slots, ring_pos, R;
+    long long steps_done;  // chunks consumed so far: the call's first new sample has absolute index steps_done * N
+    long long fwd_done;    // every block <= this one has been transformed (-1 at stream start: blocks before it are all zeros)
+    char* ring;
+    char* zeros;
+    float4* tw;
+    float4* pair;
+    float2* pair0;
+    float2* zline;
+    int pair_stride, pair0_stride;
+    int epi_op;
+    float epi_p[3];
+    bool prepared;
+    char *stage_in, *stage_out;
+    size_t stage_bytes;
+    size_t ssize() const { return cfg.sample_format == ADSP_FORMAT_F32 ? sizeof(float) : sizeof(short); }
+    size_t plane_bytes() const { return (size_t)cfg.n_channels * cfg.chunk_size * ssize(); }
+    size_t zline_bytes() const { return (size_t)cfg.n_channels * R * kB * sizeof(float2); }
+};
+
+namespace {
+long long floor_div(long long a, long long b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+int upols_launch_pair(adsp_upols* u, const void* d_in, void* d_out, int n, hipStream_t stream) {
+    const adsp_upols_config& c = u->cfg;
+    const long long N = c.chunk_size, t_call = u->steps_done * N, t_end = t_call + (long long)n * N;
+    UpolsArgs a;
+    memset(&a, 0, sizeof a);
+    a.ring = u->ring;
+    a.in = d_in;
+    a.out = d_out;
+    a.zeros = u->zeros;
+    a.tw = u->tw;
+    a.pair = u->pair;
+    a.pair0 = u->pair0;
+    a.zline = u->zline;
+    a.ring_pos = u->ring_pos;
+    a.ring_slots = u->ring_slots;
+    a.C = c.n_channels;
+    a.N = c.chunk_size;
+    a.nh = u->nh;
+    a.n_steps = n;
+    a.inv_n = 1.0f / (float)c.chunk_size;
+    a.P = c.n_partitions;
+    a.R = u->R;
+    a.ncg = c.n_channels;
+    a.pair_stride = u->pair_stride;
+    a.pair0_stride = u->pair0_stride;
+    a.epi_op = u->epi_op;
+    a.epi_p0 = u->epi_p[0];
+    a.epi_p1 = u->epi_p[1];
+    a.epi_p2 = u->epi_p[2];
+    const long long groups = ((long long)c.n_channels + 7) / 8 * 8;
+    const bool s16 = c.sample_format != ADSP_FORMAT_F32;
+    // 1. forward: the blocks whose 2B-sample windows [(b-1)B, (b+1)B) this call completes
+    const long long b_fwd_hi = floor_div(t_end, kB) - 1;
+    if (b_fwd_hi > u->fwd_done) {
+        const long long b0 = u->fwd_done + 1;
+        a.nblk = (int)(b_fwd_hi - b0 + 1);
+        a.slot_first = (int)(((b0 % u->R) + u->R) % u->R);
+        a.rel_first = (int)((b0 - 1) * kB - t_call);
+        if ((long long)a.rel_first + (long long)u->nh * N < 0) return fail(ADSP_ERR_STATE, "internal: block %lld starts before the input history", b0);
+        const long long grid = groups * a.nblk;
+        if (grid > 0x7fffffffLL) return fail(ADSP_ERR_ARG, "launch too large (%lld workgroups)", grid);
+        if (s16) hipLaunchKernelGGL((upols_forward_kernel<UPL, true>), dim3((unsigned)grid), dim3(UPL::T), kLds, stream, a);
+        else hipLaunchKernelGGL((upols_forward_kernel<UPL, false>), dim3((unsigned)grid), dim3(UPL::T), kLds, stream, a);
+        HIP_TRY(hipGetLastError());
+        u->fwd_done = b_fwd_hi;
+    }
+    // 2. multiply-accumulate + inverse: the blocks of y that meet this call's outputs, y index tau - delay for tau in [t_call, t_end)
+    const long long b_lo = floor_div(t_call - c.delay, kB), b_hi = floor_div(t_end - c.delay - 1, kB);
+    if (b_hi > u->fwd_done) return fail(ADSP_ERR_STATE, "internal: output block %lld needs input that has not arrived", b_hi);
+    if (u->fwd_done - (b_lo - c.n_partitions + 1) >= u->R) return fail(ADSP_ERR_STATE, "internal: the delay line is too short for this call");
+    a.nblk = (int)(b_hi - b_lo + 1);
+    a.slot_first = (int)(((b_lo % u->R) + u->R) % u->R);
+    a.rel_first = (int)(b_lo * kB + c.delay - t_call);  // output time of the block's first kept sample (circular index B)
+    const long long grid = groups * a.nblk;
+    if (grid > 0x7fffffffLL) return fail(ADSP_ERR_ARG, "launch too large (%lld workgroups)", grid);
+    if (s16) hipLaunchKernelGGL((upols_mac_kernel<UPL, true>), dim3((unsigned)grid), dim3(UPL::T), kLds, stream, a);
+    else hipLaunchKernelGGL((upols_mac_kernel<UPL, false>), dim3((unsigned)grid), dim3(UPL::T), kLds, stream, a);
+    HIP_TRY(hipGetLastError());
+    // 3. the ring keeps the last nh chunks (read by the next call's forward launch): stream-ordered copies behind the kernels
+    const size_t plane = u->plane_bytes();
+    const int cnt = n < u->nh ? n : u->nh;
+    for (int i = 0; i < cnt; ++i) {
+        const int slot = (u->ring_pos + 1 + i) % u->ring_slots;
+        HIP_TRY(hipMemcpyAsync(u->ring + (size_t)slot * plane, static_cast<const char*>(d_in) + (size_t)(n - cnt + i) * plane, plane, hipMemcpyDefault, stream));
+    }
+    u->ring_pos = (u->ring_pos + cnt) % u->ring_slots;
+    u->steps_done += n;
+    return ADSP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int adsp_upols_block_size(void) { return kB; }
+
+int adsp_upols_create(const adsp_upols_config* cfg, const float* spectra, adsp_upols** out) {
+    if (!cfg || !spectra || !out) return fail(ADSP_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    if (cfg->block_size != kB) return fail(ADSP_ERR_ARG, "block_size %d: this build partitions into blocks of %d samples (adsp_upols_block_size)", cfg->block_size, kB);
+    if (cfg->chunk_size < 16 || cfg->chunk_size % 4) return fail(ADSP_ERR_ARG, "chunk_size %d: partitioned engines need a multiple of 4, >= 16", cfg->chunk_size);
+    if (cfg->n_channels <= 0) return fail(ADSP_ERR_ARG, "n_channels must be positive");
+    if (cfg->n_partitions < 1 || cfg->n_partitions > 4096) return fail(ADSP_ERR_ARG, "n_partitions %d out of range 1..4096", cfg->n_partitions);
+    if (cfg->delay < kB || cfg->delay % 4)
+        return fail(ADSP_ERR_ARG, "delay %d: must be a multiple of 4 and >= the block size %d (an output block may only need input that has arrived)", cfg->delay, kB);
+    if (cfg->sample_format != ADSP_FORMAT_F32 && cfg->sample_format != ADSP_FORMAT_S16)
+        return fail(ADSP_ERR_ARG, "sample_format %d: ADSP_FORMAT_F32 or ADSP_FORMAT_S16", cfg->sample_format);
+    if (cfg->max_steps < 1) return fail(ADSP_ERR_ARG, "max_steps must be positive");
+    const long long span = (long long)cfg->max_steps * cfg->chunk_size + cfg->delay + 4LL * kB;
+    if (span >= 0x7fffffffLL) return fail(ADSP_ERR_ARG, "max_steps %d x chunk %d + delay is too long for one launch", cfg->max_steps, cfg->chunk_size);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(ADSP_ERR_NO_DEVICE, "no HIP device");
+    }
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(ADSP_ERR_ARG, "device_id %d out of range (%d devices)", cfg->device_id, ndev);
+    adsp_upols* u = new adsp_upols();
+    memset(static_cast<void*>(u), 0, sizeof *u);
+    u->cfg = *cfg;
+    const int N = cfg->chunk_size;
+    u->nh = (2 * kB + N - 1) / N;  // the oldest window a call opens starts less than two blocks before the call's first sample
+    u->ring_slots = u->nh + 1;
+    u->ring_pos = u->ring_slots - 1;
+    // blocks b_lo - P + 1 .. fwd_done of a call must be distinct slots: see upols_launch_pair
+    u->R = (int)(((long long)cfg->max_steps * N + cfg->delay + kB - 1) / kB) + cfg->n_partitions + 3;
+    u->steps_done = 0;
+    u->fwd_done = -1;
+    auto bail = [&](int code) {
+        adsp_upols_destroy(u);
+        return code;
+    };
+    hipError_t err;
+    if ((err = hipSetDevice(cfg->device_id)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(err)));
+    for (const void* fn : {reinterpret_cast<const void*>(&upols_forward_kernel<UPL, false>), reinterpret_cast<const void*>(&upols_forward_kernel<UPL, true>),
+                           reinterpret_cast<const void*>(&upols_mac_kernel<UPL, false>), reinterpret_cast<const void*>(&upols_mac_kernel<UPL, true>)})
+        if ((err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLds)) != hipSuccess)
+            return bail(fail(ADSP_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(err)));
+    const size_t ring_bytes = (size_t)u->ring_slots * u->plane_bytes();
+    if ((err = hipMalloc(&u->ring, ring_bytes)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc ring (%zu bytes): %s", ring_bytes, hipGetErrorString(err)));
+    if ((err = hipMemset(u->ring, 0, ring_bytes)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMemset: %s", hipGetErrorString(err)));
+    if ((err = hipMalloc(&u->zeros, (size_t)N * sizeof(float))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
+    if ((err = hipMemset(u->zeros, 0, (size_t)N * sizeof(float))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMemset: %s", hipGetErrorString(err)));
+    if ((err = hipMalloc(&u->zline, u->zline_bytes())) != hipSuccess)
+        return bail(fail(ADSP_ERR_HIP, "hipMalloc delay line (%zu bytes = %d channels x %d blocks x %d bytes): %s", u->zline_bytes(), cfg->n_channels, u->R,
+                         (int)(kB * sizeof(float2)), hipGetErrorString(err)));
+    if ((err = hipMemset(u->zline, 0, u->zline_bytes())) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMemset: %s", hipGetErrorString(err)));
+    // tables: the plan's twiddles, and per partition the pair tables of its spectrum - built exactly like an engine's
+    const PlanInfo pl = upols_plan_shape();
+    std::vector<float4> tw;
+    build_twiddles<float>(pl, tw);
+    if ((int)tw.size() != pl.tw_total) return bail(fail(ADSP_ERR_STATE, "internal: twiddle count %zu != %d", tw.size(), pl.tw_total));
+    tw.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+    if ((err = hipMalloc(&u->tw, tw.size() * sizeof(float4))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
+    if ((err = hipMemcpy(u->tw, tw.data(), tw.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess)
+        return bail(fail(ADSP_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(err)));
+    std::vector<float4> tab, all;
+    std::vector<float2> tab0, all0;
+    for (int p = 0; p < cfg->n_partitions; ++p) {
+        build_pair_tables<float, float>(pl, kB, spectra + (size_t)p * 2 * (kB + 1), false, tab, tab0);
+        if (p == 0) {
+            u->pair_stride = (int)tab.size();
+            u->pair0_stride = (int)tab0.size();
+        }
+        all.insert(all.end(), tab.begin(), tab.end());
+        all0.insert(all0.end(), tab0.begin(), tab0.end());
+    }
+    if ((err = hipMalloc(&u->pair, all.size() * sizeof(float4))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
+    if ((err = hipMalloc(&u->pair0, all0.size() * sizeof(float2))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
+    if ((err = hipMemcpy(u->pair, all.data(), all.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess ||
+        (err = hipMemcpy(u->pair0, all0.data(), all0.size() * sizeof(float2), hipMemcpyHostToDevice)) != hipSuccess)
+        return bail(fail(ADSP_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(err)));
+    *out = u;
+    return ADSP_OK;
+}
+
+void adsp_upols_destroy(adsp_upols* u) {
+    if (!u) return;
+    (void)hipSetDevice(u->cfg.device_id);
+    (void)hipDeviceSynchronize();
+    for (void* p : {(void*)u->ring, (void*)u->zeros, (void*)u->tw, (void*)u->pair, (void*)u->pair0, (void*)u->zline, (void*)u->stage_in, (void*)u->stage_out})
+        if (p) (void)hipFree(p);
+    delete u;
+}
+
+int adsp_upols_reset(adsp_upols* u) {
+    if (!u) return fail(ADSP_ERR_ARG, "NULL engine");
+    HIP_TRY(hipSetDevice(u->cfg.device_id));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(u->ring, 0, (size_t)u->ring_slots * u->plane_bytes()));
+    HIP_TRY(hipMemset(u->zline, 0, u->zline_bytes()));
+    u->ring_pos = u->ring_slots - 1;
+    u->steps_done = 0;
+    u->fwd_done = -1;
+    return ADSP_OK;
+}
+
+int adsp_upols_set_epilogue(adsp_upols* u, int effect, float p0, float p1, float p2) {
+    if (!u) return fail(ADSP_ERR_ARG, "NULL engine");
+    if (effect < ADSP_EFFECT_NONE || effect > ADSP_EFFECT_BIT_CRUSHER) return fail(ADSP_ERR_ARG, "unknown effect %d", effect);
+    if (effect == ADSP_EFFECT_TREMOLO) return fail(ADSP_ERR_ARG, "the tremolo's per-channel time base is only available fused on a single-transform engine");
+    if (effect != ADSP_EFFECT_NONE && u->cfg.sample_format != ADSP_FORMAT_F32) return fail(ADSP_ERR_ARG, "fused effects need a float32 engine");
+    u->epi_op = effect;
+    u->epi_p[0] = p0;
+    u->epi_p[1] = p1;
+    u->epi_p[2] = p2;
+    return ADSP_OK;
+}
+
+int adsp_upols_info(const adsp_upols* u, int* history_chunks, int* delay_line_blocks, size_t* delay_line_bytes) {
+    if (!u) return fail(ADSP_ERR_ARG, "NULL engine");
+    if (history_chunks) *history_chunks = u->nh;
+    if (delay_line_blocks) *delay_line_blocks = u->R;
+    if (delay_line_bytes) *delay_line_bytes = u->zline_bytes();
+    return ADSP_OK;
+}
+
+int adsp_upols_apply_device(adsp_upols* u, const void* d_in, void* d_out, int n_steps, void* stream) {
+    if (!u || !d_in || !d_out) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (n_steps <= 0) return fail(ADSP_ERR_ARG, "n_steps must be positive");
+    HIP_TRY(hipSetDevice(u->cfg.device_id));
+    const size_t plane = u->plane_bytes();
+    for (int done = 0; done < n_steps;) {  // at most max_steps chunks per launch pair (the delay line is sized for that)
+        const int n = n_steps - done < u->cfg.max_steps ? n_steps - done : u->cfg.max_steps;
+        const int rc = upols_launch_pair(u, static_cast<const char*>(d_in) + (size_t)done * plane, static_cast<char*>(d_out) + (size_t)done * plane, n,
+                                         static_cast<hipStream_t>(stream));
+        if (rc) return rc;
+        done += n;
+    }
+    return ADSP_OK;
+}
+
+int adsp_upols_apply_host(adsp_upols* u, const void* in, void* out, int n_steps) {
+    if (!u || !in || !out) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (n_steps <= 0) return fail(ADSP_ERR_ARG, "n_steps must be positive");
+    HIP_TRY(hipSetDevice(u->cfg.device_id));
+    const size_t bytes = (size_t)n_steps * u->plane_bytes();
+    if (bytes > u->stage_bytes) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (u->stage_in) (void)hipFree(u->stage_in);
+        if (u->stage_out) (void)hipFree(u->stage_out);
+        u->stage_in = u->stage_out = nullptr;
+        u->stage_bytes = 0;
+        HIP_TRY(hipMalloc(&u->stage_in, bytes));
+        HIP_TRY(hipMalloc(&u->stage_out, bytes));
+        u->stage_bytes = bytes;
+    }
+    HIP_TRY(hipMemcpy(u->stage_in, in, bytes, hipMemcpyHostToDevice));
+    const int rc = adsp_upols_apply_device(u, u->stage_in, u->stage_out, n_steps, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, u->stage_out, bytes, hipMemcpyDeviceToHost));
+    return ADSP_OK;
+}
+
+}  // extern "C"

@@ -270,6 +270,38 @@ def partition(fir: FirStream, max_taps: int = 14336):
     return parts
 
 
+@dataclass
+class UniformPartition:
+    """A long FIR cut for the uniformly partitioned engines (include/adsp.h, adsp_upols_*): out[tau] = y[tau - delay] with
+    y = (shift zeros + taps) (*) s, the delayed kernel cut into n_partitions pieces of `block` taps."""
+    block: int
+    n_partitions: int
+    delay: int          # multiple of 4
+    shift: int          # 0..3 taps of extra kernel delay that make `delay` a multiple of 4
+    spectra: np.ndarray  # float32 [n_partitions, block + 1, 2]: rfft of each piece zero-padded to 2 * block
+
+
+def partition_uniform(fir: FirStream, block: int, gain: float = 1.0) -> UniformPartition:
+    """Cut `fir` into partitions of `block` taps.  The stream delay fir.delay (= latency_chunks * N - lookahead) is rounded DOWN to a
+    multiple of 4 samples - the kernels move four samples per access - by delaying the kernel by the remainder instead (0..3 leading
+    zero taps).  Raises ValueError where the engines' conditions do not hold (chunk not a multiple of 4, delay shorter than a block:
+    an output block could then need input that has not arrived)."""
+    n = int(fir.chunk_size)
+    if n % 4 or n < 16:
+        raise ValueError(f"chunk_size {n}: the partitioned engines need a multiple of 4, >= 16")
+    d_total = int(fir.delay)
+    shift = d_total % 4
+    delay = d_total - shift
+    if delay < block:
+        raise ValueError(f"stream delay {d_total} is shorter than a block of {block} samples")
+    taps = np.concatenate([np.zeros(shift), np.asarray(fir.taps, dtype=np.float64) * gain])
+    parts = -(-len(taps) // block)
+    padded = np.zeros(parts * block)
+    padded[:len(taps)] = taps
+    spec = np.fft.rfft(padded.reshape(parts, block), 2 * block, axis=1).astype(np.complex64)
+    return UniformPartition(int(block), int(parts), int(delay), int(shift), np.ascontiguousarray(spec).view(np.float32).reshape(parts, block + 1, 2))
+
+
 def engine_spectrum(fir: FirStream, geo: Geometry, gain: float = 1.0, dtype=np.float32) -> np.ndarray:
     """rfft of the (shift-delayed) kernel at F points, float64 -> complex64, as interleaved float32
     (dtype=np.float64: complex128 as interleaved float64, for the float64 engines).

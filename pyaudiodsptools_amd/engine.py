@@ -9,7 +9,7 @@ import ctypes
 import numpy as np
 
 from . import _capi
-from .design import PCM16_GAIN, FirStream, engine_spectrum, fits_one_transform, overlap_save_geometry, partition
+from .design import PCM16_GAIN, FirStream, engine_spectrum, fits_one_transform, overlap_save_geometry, partition, partition_uniform
 
 _FORMATS = {"f32": (_capi.ADSP_FORMAT_F32, np.float32), "s16": (_capi.ADSP_FORMAT_S16, np.int16),
             "s16_f64": (_capi.ADSP_FORMAT_S16_F64, np.int16)}  # int16 samples, float64 arithmetic (the exact-FFT engines)
@@ -448,6 +448,78 @@ class PartitionedFirEngine:
         self.engines[0].synchronize(stream)
 
 
+class UpolsFirEngine:
+    """A FIR longer than one transform as ONE uniformly partitioned engine (adsp_upols_*, csrc/adsp_upols.hip): every input block of
+    B = 8192 samples is transformed once, its spectrum kept in a frequency-domain delay line in HBM, and an output block is one
+    inverse transform of sum_p X_{b-p} H_p - two launches per call instead of PartitionedFirEngine's full engine pass per kernel
+    slice.  float32 or int16 batches, a stateless effect fused on the output registers.  The reference shape: Example4.py:5 /
+    ModuleTestsGPU.py:35 (chunk 88200: 44 099 / 88 197 taps)."""
+
+    def __init__(self, fir: FirStream, channels=1, device=0, sample_format="f32", max_steps=1, optimize_for="stream"):
+        self._lib = _capi.load()
+        self._h = ctypes.c_void_p(None)
+        if sample_format not in ("f32", "s16"):
+            raise ValueError("sample_format must be 'f32' or 's16'")
+        self.fir, self.sample_format = fir, sample_format
+        self._fmt_code, self.dtype = _FORMATS[sample_format]
+        self.gain = PCM16_GAIN if sample_format == "s16" else 1.0
+        self.channels, self.chunk_size, self.device = int(channels), int(fir.chunk_size), int(device)
+        self.block = int(self._lib.adsp_upols_block_size())
+        self.partition = part = partition_uniform(fir, self.block, self.gain)
+        self.max_steps = int(max_steps)
+        cfg = _capi.AdspUpolsConfig(self.device, self.chunk_size, self.channels, self.block, part.n_partitions, part.delay, self._fmt_code,
+                                    self.max_steps)
+        spectra = np.ascontiguousarray(part.spectra, dtype=np.float32)
+        _capi.check(self._lib.adsp_upols_create(ctypes.byref(cfg), _ptr(spectra), ctypes.byref(self._h)))
+        hist, blocks, nbytes = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_size_t(0)
+        _capi.check(self._lib.adsp_upols_info(self._h, ctypes.byref(hist), ctypes.byref(blocks), ctypes.byref(nbytes)))
+        self.history_chunks, self.delay_line_blocks, self.delay_line_bytes = hist.value, blocks.value, nbytes.value
+        self.epilogue = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.adsp_upols_destroy(self._h)
+            self._h = ctypes.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        _capi.check(self._lib.adsp_upols_reset(self._h))
+
+    def set_epilogue(self, effect=None):
+        """A stateless effect (effects.Effect; not the tremolo) applied to the output registers of the inverse transform."""
+        op, (p0, p1, p2) = (effect.op, effect.params()) if effect is not None else (_capi.EFFECT_NONE, (0.0, 0.0, 0.0))
+        if op == _capi.EFFECT_TREMOLO:
+            raise ValueError("the tremolo's per-channel time base is only available fused on a single-transform engine")
+        _capi.check(self._lib.adsp_upols_set_epilogue(self._h, int(op), float(p0), float(p1), float(p2)))
+        self.epilogue = effect
+
+    def apply_device(self, d_in, d_out, n_steps=1, stream=None):
+        """Device-resident [n_steps, C, N] batches of the engine's sample type, not aliased; asynchronous on `stream`."""
+        _capi.check(self._lib.adsp_upols_apply_device(self._h, _ptr(d_in), _ptr(d_out), int(n_steps), _ptr(stream)))
+
+    def apply_host(self, x):
+        if self.sample_format != "f32" and np.asarray(x).dtype != np.int16:
+            raise TypeError("this engine filters int16 PCM; pass an int16 array")
+        x = np.ascontiguousarray(x, dtype=self.dtype)
+        squeeze = x.ndim == 2
+        if squeeze:
+            x = x[None]
+        if x.ndim != 3 or x.shape[1:] != (self.channels, self.chunk_size):
+            raise ValueError(f"expected [steps, {self.channels}, {self.chunk_size}], got {x.shape}")
+        out = np.empty_like(x)
+        _capi.check(self._lib.adsp_upols_apply_host(self._h, _ptr(x), _ptr(out), x.shape[0]))
+        return out[0] if squeeze else out
+
+    def synchronize(self, stream=None):
+        import torch  # plumbing only (the engine has no synchronise entry point of its own)
+        torch.cuda.synchronize(self.device)
+
+
 class MixBus:
     """MixSignals over filtered channels in one pass each (Utility.py:51-72 after K FFT devices): engine 0 writes the
     output buffer, the others add to it, the last one clips the sum - no separate mixing pass over HBM."""
@@ -466,12 +538,18 @@ class MixBus:
 
 
 def make_engine(fir: FirStream, **kw):
-    """FirEngine when the kernel fits one transform, PartitionedFirEngine otherwise."""
+    """FirEngine when the kernel fits one transform; otherwise the uniformly partitioned engine (UpolsFirEngine: one forward transform
+    per input block, a frequency-domain delay line, one inverse per output block), and where its conditions do not hold (chunk sizes
+    that are not multiples of 4, streams delayed by less than a block) PartitionedFirEngine (one engine pass per kernel slice)."""
     if fits_one_transform(fir):
         return FirEngine(fir, **kw)
-    if kw.get("sample_format", "f32") != "f32":
-        raise ValueError("kernels longer than one transform are supported for float32 samples only")
-    kw.pop("sample_format", None)
     kw.pop("ring_slots", None)
     kw.pop("fft_mult", None)
-    return PartitionedFirEngine(fir, **kw)
+    try:
+        partition_uniform(fir, _capi.load().adsp_upols_block_size())
+    except ValueError:
+        if kw.get("sample_format", "f32") != "f32":
+            raise ValueError("kernels longer than one transform with a chunk size that is not a multiple of 4 are supported for float32 samples only")
+        kw.pop("sample_format", None)
+        return PartitionedFirEngine(fir, **kw)
+    return UpolsFirEngine(fir, **kw)

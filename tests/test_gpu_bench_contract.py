@@ -22,7 +22,7 @@ def run_bench(*extra, env=None):
 
 
 def test_default_line_has_everything_the_driver_reads():
-    d, lines = run_bench("--steps", "3", "--warmup", "1")
+    d, lines = run_bench("--steps", "3", "--warmup", "1", "--no-configs")  # (configs 4 / 5 in the line: tests/test_gpu_round5.py)
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
@@ -56,7 +56,7 @@ def test_other_workloads_and_the_rccl_path_print_the_same_line():
     assert d["config"]["kernel_taps"] == 9401 and d["config"]["outputs_per_transform"] == 22528 and d["value"] > 0
     d, _ = run_bench("--steps", "64", "--warmup", "8", "--mode", "stream", "--no-latency", "--no-cpu-baseline")
     assert d["config"]["mode"] == "stream" and d["config"]["chunks_per_step"] == 1 and d["roofline"]["launches"] == 64
-    d, lines = run_bench("--steps", "2", "--warmup", "1", "--no-stream-extra", "--no-latency", "--no-cpu-baseline",
+    d, lines = run_bench("--steps", "2", "--warmup", "1", "--no-stream-extra", "--no-latency", "--no-cpu-baseline", "--no-configs",
                          env={"ADSP_BENCH_FORCE_PG": "1", "MASTER_PORT": "29541"})  # init_process_group("nccl") at world size 1
     assert d["n_gpus"] == 1 and d["value"] > 0 and lines[-1].lstrip().startswith("{")
     # ... and the same collective once more through the C ABI (adsp_bcast_spectrum_rank), cross-checked against the torch carrier

@@ -272,31 +272,33 @@ def test_generic_chunk_sizes_vs_oracle(adsp, n, channels):
 
 
 def test_example4_chunk_size_partitioned(adsp, golden):
-    """N = 88200 (Example4.py:5): 44099 / 88197 taps do not fit one transform -> partitioned engines, summed.
-    Drop-in classes against the reference's decimated goldens; the device path (accumulating launches) against the
-    host path."""
+    """N = 88200 (Example4.py:5): 44099 / 88197 taps do not fit one transform.  Round 5: the drop-in classes run the uniformly
+    partitioned engine (one forward transform per input block, frequency-domain delay line, one inverse per output block);
+    PartitionedFirEngine (one engine pass per kernel slice, summed) stays as the checker.  Both against the reference's decimated
+    goldens, host path and device path."""
     import torch
     n = 88200
     adsp.config.initialize(44100, n)
     for dev, seed, key in ((adsp.CreateLowCutFilter(300), 91, "LC88200_dec64"),
                            (adsp.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5), 92, "EQ88200_dec64")):
-        assert type(dev.engine).__name__ == "PartitionedFirEngine" and len(dev.engine.engines) >= 4
+        assert type(dev.engine).__name__ == "UpolsFirEngine" and dev.engine.partition.n_partitions in (6, 11)
         x = seeded_stream(seed, 3 * n)
         y = np.concatenate([dev.apply(x[i * n:(i + 1) * n]) for i in range(3)])
         assert_parity(y[::64], golden["kat_streams"][key], what=key)
-        dev.reset()
-        xd = torch.from_numpy(x.reshape(3, 1, n)).cuda()
-        yd = torch.full_like(xd, 7.0)  # part 0 must overwrite, the others accumulate
-        s = torch.cuda.current_stream().cuda_stream
-        dev.engine.apply_device(xd[:2], yd[:2], 2, s)
-        dev.engine.apply_device(xd[2], yd[2], 1, s)
-        torch.cuda.synchronize()
-        assert_parity(yd.cpu().numpy().reshape(-1), y, what=key + " device path")
+        for eng in (dev.engine, adsp.PartitionedFirEngine(dev.fir)):
+            assert type(eng).__name__ != "PartitionedFirEngine" or len(eng.engines) >= 4
+            eng.reset()
+            xd = torch.from_numpy(x.reshape(3, 1, n)).cuda()
+            yd = torch.full_like(xd, 7.0)  # every sample must be overwritten (partitioned: part 0 overwrites, the others accumulate)
+            s = torch.cuda.current_stream().cuda_stream
+            eng.apply_device(xd[:2], yd[:2], 2, s)
+            eng.apply_device(xd[2], yd[2], 1, s)
+            torch.cuda.synchronize()
+            assert_parity(yd.cpu().numpy().reshape(-1), y, what=key + " device path " + type(eng).__name__)
     adsp.config.initialize(44100, 88200)
     with pytest.raises(ValueError):
         adsp.FirEngine(dev.fir, sample_format="s16")  # one engine cannot hold it ...
-    with pytest.raises(ValueError):
-        adsp.make_engine(dev.fir, sample_format="s16")  # ... and partitioning is float32 only
+    assert type(adsp.make_engine(dev.fir, sample_format="s16")).__name__ == "UpolsFirEngine"  # ... the partitioned one can (round 5)
 
 
 def test_device_pointer_and_ring_paths(adsp):

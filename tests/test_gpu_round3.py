@@ -200,7 +200,7 @@ def test_bench_single_process_mode_one_gpu():
     """bench.py --single-process: N engines in ONE process, filter shared by adsp_bcast_spectrum (no torch.distributed);
     with one GPU that is one engine, and the line says which carrier moved the spectrum."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--single-process", "--gpus", "1", "--steps", "2", "--warmup", "1",
-           "--prewarm-ms", "20", "--no-cpu-baseline", "--no-latency", "--no-stream-extra", "--chunks-per-step", "6", "--channels", "512"]
+           "--prewarm-ms", "20", "--no-cpu-baseline", "--no-latency", "--no-stream-extra", "--no-configs", "--chunks-per-step", "6", "--channels", "512"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     d = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])

@@ -190,13 +190,19 @@ def test_bench_gpus2_without_a_launcher_reexecutes_itself():
     assert set(cfgs) >= {"config4_highcut_8192ch_x_4096", "config5_chain_4096ch_x_8192_96k"}
     for c in cfgs.values():
         assert c["value"] > 0 and c["n_gpus"] == 2 and c["roofline_frac"] > 0 and c["parity_max_rel_err"] <= 1e-5
+    # ... and a world that is not what was asked for (here two ranks told to expect three) leaves with a non-zero status
+    # and NO line, on every rank
+    env["ADSP_BENCH_EXPECT_RANKS"] = "3"
+    out = subprocess.run(cmd + ["--no-configs", "--no-parity-check"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode != 0 and "ranks_seen = 2 (expected 3)" in out.stderr, out.stderr[-2000:]
+    assert not any(ln.lstrip().startswith("{") for ln in out.stdout.splitlines())
 
 
 def test_bench_single_process_line_carries_the_multi_gpu_keys():
     """--single-process (adsp_bcast_spectrum, ncclCommInitAll): with one GPU a world of one; the keys of the N > 1 line are
     there (ranks_seen, spectrum_checksum from adsp_get_spectrum)."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--single-process", "--gpus", "1", "--steps", "2", "--warmup", "1",
-           "--prewarm-ms", "20", "--no-cpu-baseline", "--no-latency", "--no-stream-extra", "--chunks-per-step", "7", "--channels", "512",
+           "--prewarm-ms", "20", "--no-cpu-baseline", "--no-latency", "--no-stream-extra", "--no-configs", "--chunks-per-step", "7", "--channels", "512",
            "--runs", "3"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]

@@ -1,0 +1,229 @@
+"""Round 5: the uniformly partitioned engine for kernels longer than one transform (Example4's chunk 88200), the
+counter-based input generator and its numpy twin, the bench line's new blocks (configs 4 / 5 at N = 1, the host oracle check, the loud
+exit on a wrong world), the live-session guards.  Run with -m gpu on MI355X."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_parity, seeded_stream
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def adsp():
+    import pyaudiodsptools_amd as pkg
+    from pyaudiodsptools_amd import _capi
+    assert _capi.device_count() >= 1, "no GPU visible: the HIP path cannot run (no CPU fallback by design)"
+    return pkg
+
+
+def orc():
+    from oracle import fftfilter_oracle as o
+    return o
+
+
+def _exact(adsp, fir, x, fmt="f32"):
+    import torch
+    ex = adsp.ExactFirEngine(fir, channels=x.shape[1], sample_format=fmt)
+    t = torch.empty_like(x)
+    ex.apply_device(x, t, x.shape[0], torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ex.close()
+    return t
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 1. Uniformly partitioned engines (csrc/adsp_upols.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,taps_len,latency,lookahead,channels,calls,max_steps", [
+    (88200, 44099, 1, 22049, 3, [1, 1, 1], 1),        # Example4's low cut geometry (Example4.py:5, EffectFFTFilter.py:91-151), random taps
+    (20000, 40000, 3, 20000, 9, [2, 1, 3], 2),        # kernel longer than two chunks, calls of several chunks, split into sub-calls
+    (12000, 33000, 4, 16000, 67, [1, 2, 1, 1], 4),    # ragged channel count (the last XCD group is partly empty), odd delay (shift 0..3)
+    (50000, 70001, 2, 12345, 1, [1, 1], 1),           # ONE channel, delay = 87655 -> 3 taps of kernel delay
+])
+def test_upols_engine_matches_the_float64_direct_sum(adsp, n, taps_len, latency, lookahead, channels, calls, max_steps):
+    """Every output sample of every channel of a long-kernel stream against the float64 direct sum computed on the GPU
+    (adsp_exact_*), and two channels against the oracle's direct_stream_convolution on the host; the same stream through
+    PartitionedFirEngine (the round 1 - 4 form) agrees."""
+    import torch
+    rng = np.random.default_rng(n + taps_len)
+    taps = rng.standard_normal(taps_len) * np.hanning(taps_len) / np.sqrt(taps_len) * 3.0
+    fir = adsp.FirStream(taps, n, latency_chunks=latency, lookahead=lookahead)
+    eng = adsp.UpolsFirEngine(fir, channels=channels, max_steps=max_steps)
+    assert eng.partition.n_partitions == -(-(taps_len + eng.partition.shift) // 8192) and eng.partition.delay % 4 == 0
+    steps = sum(calls)
+    g = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=g)
+    y = torch.full_like(x, 7.0)
+    s = torch.cuda.current_stream().cuda_stream
+    pos = 0
+    for k in calls:
+        eng.apply_device(x[pos:pos + k], y[pos:pos + k], k, s)
+        pos += k
+    torch.cuda.synchronize()
+    t = _exact(adsp, fir, x)
+    scale = float(t.abs().max())
+    assert scale > 0.1 and float((y - t).abs().max()) <= 1e-5 * scale, float((y - t).abs().max()) / scale
+    for c in sorted({0, channels - 1}):
+        ref = orc().direct_stream_convolution(taps, x[:, c].reshape(-1).cpu().numpy(), n, latency, lookahead)
+        assert_parity(y[:, c].reshape(-1).cpu().numpy(), ref, what=f"oracle channel {c}")
+    # the host path on a fresh stream, and reset
+    eng.reset()
+    yh = eng.apply_host(x[:calls[0]].cpu().numpy())
+    assert np.abs(yh - y[:calls[0]].cpu().numpy()).max() <= 2e-6 * scale
+    eng.close()
+    if channels <= 9:
+        pe = adsp.PartitionedFirEngine(fir, channels=channels)
+        yp = torch.empty_like(x)
+        pe.apply_device(x, yp, steps, s)
+        torch.cuda.synchronize()
+        assert float((yp - t).abs().max()) <= 1e-5 * scale
+        pe.close()
+
+
+def test_upols_engine_int16_and_fused_effect(adsp):
+    """int16 PCM batches (the WAV front end, Utility.py:233-238 / :295-312, fused like the ADSP_FORMAT_S16 engines: <= 1 LSB against the
+    exact engine's int16 stream) and a stateless effect on the output registers (EffectSaturator.py:27-49 after the long filter)."""
+    import torch
+    from oracle import effects_oracle as fx
+    n, taps_len = 30000, 36001
+    rng = np.random.default_rng(5)
+    taps = rng.standard_normal(taps_len) * np.hanning(taps_len) / np.sqrt(taps_len)
+    fir = adsp.FirStream(taps, n, latency_chunks=2, lookahead=18000)
+    pcm = torch.randint(-12000, 12000, (3, 5, n), device="cuda", dtype=torch.int16, generator=torch.Generator(device="cuda").manual_seed(9))
+    eng = adsp.UpolsFirEngine(fir, channels=5, sample_format="s16")
+    out = torch.empty_like(pcm)
+    eng.apply_device(pcm, out, 3, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = _exact(adsp, fir, pcm, "s16")
+    diff = (out.int() - want.int()).abs()
+    assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) <= 0.01
+    eng.close()
+    # fused saturator against the oracle's saturator applied to the exact stream
+    x = torch.empty((2, 4, n), device="cuda").uniform_(-1, 1, generator=torch.Generator(device="cuda").manual_seed(10))
+    eng = adsp.UpolsFirEngine(adsp.FirStream(taps * 4.0, n, latency_chunks=2, lookahead=18000), channels=4)
+    eng.set_epilogue(adsp.CreateSaturator())
+    y = torch.empty_like(x)
+    eng.apply_device(x, y, 2, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    t = _exact(adsp, eng.fir, x).cpu().numpy()
+    assert_parity(y.cpu().numpy(), fx.saturator(t), what="fused saturator")
+    with pytest.raises(ValueError):
+        eng.set_epilogue(adsp.CreateTremolo())
+    eng.close()
+
+
+def test_upols_raw_abi_refusals(adsp):
+    import ctypes
+    from pyaudiodsptools_amd import _capi
+    lib = _capi.load()
+    b = lib.adsp_upols_block_size()
+    spec = np.zeros((2, b + 1, 2), np.float32)
+    h = ctypes.c_void_p(None)
+    ok = dict(device_id=0, chunk_size=40000, n_channels=2, block_size=b, n_partitions=2, delay=20000, sample_format=0, max_steps=1)
+    for bad in (dict(block_size=4096), dict(chunk_size=40002), dict(delay=b - 4), dict(delay=20002), dict(n_partitions=0), dict(sample_format=2),
+                dict(max_steps=0), dict(n_channels=0), dict(device_id=99)):
+        cfg = _capi.AdspUpolsConfig(**{**ok, **bad})
+        assert lib.adsp_upols_create(ctypes.byref(cfg), spec.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)) != 0, bad
+        assert lib.adsp_last_error()
+    cfg = _capi.AdspUpolsConfig(**ok)
+    assert lib.adsp_upols_create(ctypes.byref(cfg), spec.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)) == 0
+    assert lib.adsp_upols_apply_device(h, None, None, 1, None) != 0 and lib.adsp_upols_set_epilogue(h, 5, 0.4, 1e-4, 100.0) != 0
+    lib.adsp_upols_destroy(h)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 2. The counter-based generator and its numpy twin
+# ---------------------------------------------------------------------------------------------------------------------
+def test_synth_device_equals_its_numpy_twin_bit_for_bit(adsp):
+    import torch
+    from pyaudiodsptools_amd import synth
+    for fmt, dt in (("f32", torch.float32), ("s16", torch.int16)):
+        for (c0, t0, C, N, steps, amp) in ((0, 0, 5, 64, 3, 1.0), (4090, (1 << 33) + 12, 7, 4096, 2, 1.0), (17, 123456, 3, 1000, 4, 0.25)):
+            d = torch.empty((steps, C, N), device="cuda", dtype=dt)
+            synth.fill_device(d, 1234, c0, t0, C, N, steps, fmt, amp)
+            torch.cuda.synchronize()
+            want = synth.batch_host(1234, c0, C, t0, N, steps, fmt, amp)
+            assert np.array_equal(d.cpu().numpy(), want), (fmt, c0, t0)
+    u = synth.uniform_host(1234, 3, 0, 1 << 16)
+    assert u.dtype == np.float32 and -1.0 <= u.min() < -0.99 and 0.99 < u.max() < 1.0 and abs(float(u.mean())) < 0.02
+    assert abs(float(np.corrcoef(u[:-1], u[1:])[0, 1])) < 0.02 and abs(float(np.corrcoef(u, synth.uniform_host(1234, 4, 0, 1 << 16))[0, 1])) < 0.02
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 3. bench.py: configs 4 / 5 in the N = 1 line, the oracle check, the loud exit
+# ---------------------------------------------------------------------------------------------------------------------
+def _bench(*extra, env=None, check=True):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--channels", "256", "--chunks-per-step", "12", "--prewarm-ms", "20", "--cpu-seconds", "0.2", *extra]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env={**os.environ, **(env or {})})
+    if check:
+        assert out.returncode == 0, out.stderr[-2000:]
+    return out
+
+
+def test_bench_n1_line_carries_configs_4_and_5_with_their_rooflines_and_the_oracle_check():
+    out = _bench("--steps", "3", "--warmup", "1", "--no-stream-extra", "--no-latency", "--no-cpu-baseline")
+    d = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.strip()][-1])
+    assert d["oracle_checked"] is True and 0.0 <= d["oracle_check"]["max_rel_err"] <= 1e-5 and len(d["oracle_check"]["channels"]) == 2
+    assert d["oracle_check"]["samples"] >= 2 * 2 * 3 * 4096 and "direct_stream_convolution" in d["oracle_check"]["against"]
+    for key, taps in (("config4_highcut_8192ch_x_4096", 2047), ("config5_chain_4096ch_x_8192_96k", 9401)):
+        c = d["configs"][key]
+        assert "error" not in c, c
+        assert c["n_gpus"] == 1 and c["value"] > 0 and c["runs"] == 3 and len(c["runs_msamples_s"]) == 3 and f"{taps} taps" in c["workload"]
+        assert c["parity_checked"] is True and c["parity_max_rel_err"] <= 1e-5 and c["oracle_max_rel_err"] <= 1e-5
+        r = c["roofline"]
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["launches"] == c["steps"]
+        assert abs(r["achieved"] * 1e9 - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6)) <= 2e-3 * r["achieved"] * 1e9
+    assert d["data"].startswith("synthetic uniform(-1,1) float32")
+
+
+def test_bench_exits_non_zero_without_a_line_when_the_world_is_not_what_was_asked_for():
+    """a job whose process group is smaller than --gpus N (or whose ranks ended up with different filters) must not print
+    a line the driver could take for an N-GPU measurement.  Simulated on one GPU: a world of one that was told to expect two."""
+    out = _bench("--steps", "2", "--warmup", "1", "--no-stream-extra", "--no-latency", "--no-cpu-baseline", "--no-configs",
+                 env={"ADSP_BENCH_FORCE_PG": "1", "MASTER_PORT": "29547", "ADSP_BENCH_EXPECT_RANKS": "2", "ADSP_BENCH_ABI_CHECK": "0"}, check=False)
+    assert out.returncode == 3 and "ranks_seen = 1 (expected 2)" in out.stderr
+    assert not any(ln.lstrip().startswith("{") for ln in out.stdout.splitlines())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 4. Live-session guards and the inspectable attributes of the drop-in classes
+# ---------------------------------------------------------------------------------------------------------------------
+def test_live_session_refuses_ring_and_configuration_calls(adsp):
+    import ctypes
+    import torch
+    from pyaudiodsptools_amd import FirEngine, FirStream, design, _capi
+    n = 512
+    fir = FirStream(design.lowcut_kernel(300, 44100, n), n)
+    eng = FirEngine(fir, channels=8, ring_slots=12)
+    out = torch.empty((4, 8, n), device="cuda")
+    eng.live_configure(step_timeout_ms=2000.0)
+    eng.live_start(out, 4, 100, None)
+    lib = _capi.load()
+    p = ctypes.c_void_p(None)
+    for call in (lambda: lib.adsp_ring_produce_begin(eng._h, ctypes.byref(p), None), lambda: lib.adsp_ring_produce_end(eng._h, None),
+                 lambda: lib.adsp_apply_ring_resident(eng._h, ctypes.c_void_p(out.data_ptr()), 1, None), lambda: lib.adsp_set_accumulate(eng._h, 1),
+                 lambda: lib.adsp_set_epilogue(eng._h, 1, 0.5, 0.0, 0.0), lambda: lib.adsp_set_block_outputs(eng._h, n)):
+        assert call() == _capi.ADSP_ERR_STATE and b"live session" in lib.adsp_last_error()
+    assert eng.live_stop() == 0
+    eng.close()
+
+
+def test_filtered_signal_and_original_signal_mirror_the_reference(adsp):
+    """EffectFFTFilter.py:39 / :67-73 and EffectEQ3BandFFT.py:147-148 / :175-176."""
+    n = 512
+    adsp.config.initialize(44100, n)
+    lc, eq = adsp.CreateLowCutFilter(200), adsp.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5)
+    assert lc.filtered_signal.shape == (3 * n,) and not lc.filtered_signal.any()
+    assert eq.filtered_signal.shape == (3 * n,) and eq.original_signal.shape == (3 * n,) and not eq.original_signal.any()
+    x = seeded_stream(3, 2 * n)
+    y0, y1 = lc.apply(x[:n]), lc.apply(x[n:])
+    assert lc.filtered_signal.dtype == np.complex128 and np.array_equal(lc.filtered_signal.real.astype(np.float32), y1) and y0.shape == (n,)
+    eq.apply(x[:n])
+    eq.apply(x[n:])
+    assert np.array_equal(eq.original_signal, np.concatenate([np.zeros(n), x[:n], x[n:]])) and not eq.filtered_signal.any()
