@@ -674,6 +674,99 @@ def numpy_api_latency(n=4096, reps=1500):
     return (time.perf_counter() - t0) / reps * 1e6
 
 
+def host_batch_figures(dev, gib=1.0, files=256, seconds_per_file=10):
+    """The numpy API on REAL batches (host arrays in, host arrays out - the reference's contract, EffectFFTFilter.py:49-75, for many
+    channels and chunks per call): FirEngine.apply_host on a `gib` GiB float32 batch (4096 channels x 4096 samples x 16 chunks) and
+    WavBank.process on `files` mono 16-bit WAV files, against the PCIe Gen5 x16 link (63 GB/s per direction, MI355X_MICROARCH.md).
+    Large host calls move in slabs through double-buffered pinned staging, H2D / kernel / D2H overlapped (adsp_apply_host); the
+    one-piece form it replaced (pageable hipMemcpy in, kernel, hipMemcpy out) is timed beside it (ADSP_HOST_UNPIPELINED=1)."""
+    import tempfile
+    import torch
+    import wave
+    from pyaudiodsptools_amd import FirEngine, WavBank, config, design, synth as asynth
+    n, C, fs = 4096, 4096, 44100
+    steps = max(4, int(gib * 2 ** 30 / (C * n * 4)))
+    fir = design.FirStream(design.lowcut_kernel(800, fs, n), n)
+    eng = FirEngine(fir, channels=C, device=dev.index, optimize_for="batch")
+    xd = torch.empty((steps, C, n), device=dev)
+    asynth.fill_device(xd, 4321, 0, 0, C, n, steps, "f32", 1.0, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    yd = torch.empty_like(xd)
+    eng.apply_device(xd, yd, steps, torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    x = xd.cpu().numpy()
+    ref = yd[:, ::509].cpu().numpy()  # every 509th channel of the device-resident result
+    del xd, yd
+    torch.cuda.empty_cache()
+    out = np.empty_like(x)
+    nbytes = x.nbytes
+
+    def timed(reps):
+        ts = []
+        for _ in range(reps):
+            eng.reset()
+            t0 = time.perf_counter()
+            eng.apply_host(x, out=out)
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2]
+    timed(1)  # staging buffers, page faults of `out`
+    t_pipe = timed(3)
+    err = float(np.abs(out[:, ::509] - ref).max() / max(np.abs(ref).max(), 1e-30))
+    os.environ["ADSP_HOST_UNPIPELINED"] = "1"
+    try:
+        timed(1)
+        t_plain = timed(2)
+    finally:
+        del os.environ["ADSP_HOST_UNPIPELINED"]
+    res = {"apply_host_1gib": {"batch": f"[{steps}, {C}, {n}] float32 = {nbytes / 2 ** 30:.2f} GiB in, the same out", "seconds": round(t_pipe, 4),
+                               "gb_per_s_each_direction": round(nbytes / t_pipe / 1e9, 2), "link_gb_per_s": 63.0,
+                               "frac_of_link": round(nbytes / t_pipe / 1e9 / 63.0, 3), "msamples_s": round(steps * C * n / t_pipe / 1e6, 1),
+                               "unpipelined_seconds": round(t_plain, 4), "unpipelined_gb_per_s_each_direction": round(nbytes / t_plain / 1e9, 2),
+                               "max_rel_err_vs_device_path": float(f"{err:.3e}"),
+                               "note": "FirEngine.apply_host(x, out=out), out reused; median of 3; the host side (pageable -> pinned copies by a few threads) and "
+                                       "the link bound it, never the kernel"}}
+    del eng, x, out
+    # WavBank.process: many 16-bit WAV files -> one int16 batch -> one host call -> int16 per file (Example1 / Example2 for many files)
+    config.initialize(fs, n)
+    tmp = tempfile.mkdtemp(prefix="adsp_bench_wav_")
+    try:
+        frames = fs * seconds_per_file // 4 * 4
+        pcm_dev = torch.empty((1, files, frames), device=dev, dtype=torch.int16)  # file i = channel i of the counter-based generator, seed 99
+        asynth.fill_device(pcm_dev, 99, 0, 0, files, frames, 1, "s16", 1.0, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        pcm_all = pcm_dev[0].cpu().numpy()
+        del pcm_dev
+        paths = []
+        for i in range(files):
+            p = os.path.join(tmp, f"f{i:04d}.wav")
+            with wave.open(p, "wb") as w:
+                w.setnchannels(1)
+                w.setsampwidth(2)
+                w.setframerate(fs)
+                w.writeframes(pcm_all[i].tobytes())
+            paths.append(p)
+        del pcm_all
+        t0 = time.perf_counter()
+        bank = WavBank(paths, n)
+        t_read = time.perf_counter() - t0
+        bank.process(fir)  # first call: engine creation, staging buffers
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            outs = bank.process(fir)
+            ts.append(time.perf_counter() - t0)
+        t_proc = min(ts)
+        pcm_bytes = bank.pcm.nbytes
+        assert len(outs) == files and outs[0].dtype == np.int16 and outs[0].any()
+        res["wavbank_process"] = {"files": files, "seconds_of_audio_per_file": seconds_per_file, "pcm_gib": round(pcm_bytes / 2 ** 30, 3),
+                                  "read_and_pack_seconds": round(t_read, 3), "process_seconds": round(t_proc, 4),
+                                  "gb_per_s_each_direction": round(pcm_bytes / t_proc / 1e9, 2), "msamples_s": round(pcm_bytes / 2 / t_proc / 1e6, 1),
+                                  "note": "WavBank.process(fir): batch() transposition + engine creation + apply_host (int16, 4 bytes per sample over the "
+                                          "link) + per-file views; file reading is not part of process()"}
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    return res
+
+
 def reexec_under_launcher(args):
     """`python3 bench.py --gpus N` with no launcher around it: bench.py becomes its own launcher - it replaces itself by
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> bench.py
@@ -943,8 +1036,13 @@ def main():
             if "one_stream" in s3:
                 c3["pipelined"] = {k: s3[k] for k in ("us_per_step", "value", "roofline_frac", "runs_us_per_step") if k in s3}
             c3.update({k: s3[k] for k in ("resident", "resident_live") if k in s3})
+            try:
+                host_batches = host_batch_figures(dev) if not getattr(args, "small", False) and args.channels >= 1024 else None
+            except Exception as exc:
+                host_batches = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             latency = {"config3_eq3_2048_stereo_pairs_x_512": c3,
                        "numpy_api_apply_us_per_call": round(numpy_api_latency(), 2),
+                       "numpy_api": host_batches,
                        "note": "config 3 = CreateEQ3BandFFT(100,2,700,-4,8000,5) on 4096 mono channels (2048 stereo pairs) x 512 samples, one launch "
                                "per step (zero-copy ring); numpy API = CreateLowCutFilter(800).apply(float32[4096]) -> float32[4096], 1 channel, host "
                                "buffers (PCIe + launch bound, never `value`)"}

@@ -10,7 +10,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -232,6 +234,17 @@ struct adsp_engine {
     char* stage_in;
     char* stage_out;
     size_t stage_elems;  // capacity in samples
+    // large host calls (round 5): the batch moves in slabs through double-buffered pinned staging - the H2D copy of slab i + 1 and the D2H
+    // copy of slab i - 1 run on copy streams of their own beside the kernel of slab i (apply_host_pipelined)
+    struct HostPipe {
+        char* pin_in[2] = {nullptr, nullptr};
+        char* pin_out[2] = {nullptr, nullptr};
+        char* d_in[2] = {nullptr, nullptr};
+        char* d_out[2] = {nullptr, nullptr};
+        size_t slab_bytes = 0;
+        hipStream_t s_in = nullptr, s_k = nullptr, s_out = nullptr;
+        hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    } hp;
     // small host calls skip the staging copies: the kernel reads a pinned, device-mapped copy of the caller's input
     // and writes the result straight into pinned host memory (two input slots: the ring update of call k may still be
     // reading slot k % 2 while the caller fills the other)
@@ -677,6 +690,14 @@ int adsp_destroy(adsp_engine* e) {
     if (e->ev_copy_done) (void)hipEventDestroy(e->ev_copy_done);
     if (e->stage_in) (void)hipFree(e->stage_in);
     if (e->stage_out) (void)hipFree(e->stage_out);
+    for (char* p : {e->hp.d_in[0], e->hp.d_in[1], e->hp.d_out[0], e->hp.d_out[1]})
+        if (p) (void)hipFree(p);
+    for (char* p : {e->hp.pin_in[0], e->hp.pin_in[1], e->hp.pin_out[0], e->hp.pin_out[1]})
+        if (p) (void)hipHostFree(p);
+    for (hipStream_t st : {e->hp.s_in, e->hp.s_k, e->hp.s_out})
+        if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t ev : {e->hp.ev_in[0], e->hp.ev_in[1], e->hp.ev_k[0], e->hp.ev_k[1], e->hp.ev_out[0], e->hp.ev_out[1]})
+        if (ev) (void)hipEventDestroy(ev);
     for (char* p : {e->pin_in[0], e->pin_in[1], e->pin_out, e->pin_tab[0], e->pin_tab[1]})
         if (p) (void)hipHostFree(p);
     for (hipEvent_t ev : {e->ev_tab[0], e->ev_tab[1]})
@@ -1976,14 +1997,156 @@ int apply_host_direct(adsp_engine* e, const void* in, void* out, int n_steps, si
 }
 }  // namespace
 
+namespace {
+// host memory moved by a few threads at once: one core copies ~10 GB/s, the link takes 63 GB/s each way
+void parallel_memcpy(char* dst, const char* src, size_t bytes, int threads) {
+    if (threads <= 1 || bytes < (8u << 20)) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t part = ((bytes / threads) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) {
+        const size_t off = (size_t)t * part;
+        if (off >= bytes) break;
+        pool.emplace_back([=] { memcpy(dst + off, src + off, off + part <= bytes ? part : bytes - off); });
+    }
+    memcpy(dst, src, part < bytes ? part : bytes);
+    for (auto& th : pool) th.join();
+}
+
+constexpr size_t kPipeSlabTarget = 48u << 20;  // bytes per slab and direction: four pinned + four device buffers of this size per engine
+
+// Large host batches (the numpy API on a real batch: WavBank.process, apply_batch - EffectFFTFilter.py:49-75 for C channels and many
+// chunks at once): slabs of whole steps through double-buffered pinned staging.  Three threads of control on the host - a stager that
+// fills pin_in, this thread that enqueues copies and launches, a drainer that empties pin_out - and three streams on the device, so
+// that the H2D copy of slab i + 1, the kernel of slab i and the D2H copy of slab i - 1 overlap, and so do the host's own copies in
+// and out of pinned memory.  Steps are independent through the engine's history ring, so a slab is just a shorter call.
+int apply_host_pipelined(adsp_engine* e, const char* in, char* out, int n_steps) {
+    adsp_engine::HostPipe& hp = e->hp;
+    const size_t step_bytes = e->plane_bytes();
+    int slab_steps = (int)(kPipeSlabTarget / step_bytes);
+    if (slab_steps < 1) slab_steps = 1;
+    if (slab_steps > (n_steps + 3) / 4) slab_steps = (n_steps + 3) / 4;  // at least four slabs
+    if (!e->generic && e->block_outputs > e->cfg.chunk_size) {
+        // multi-step launches tile the time axis with block_outputs kept samples: whole tiles per slab (a slab's last block is then full)
+        long long tile = e->block_outputs, g = e->cfg.chunk_size;
+        for (long long a = tile, b = g; b;) { const long long t = a % b; a = b; b = t; g = a; }
+        const int tile_steps = (int)(tile / g);  // lcm(block_outputs, N) / N
+        if (slab_steps >= tile_steps) slab_steps = slab_steps / tile_steps * tile_steps;
+    }
+    const size_t slab_bytes = (size_t)slab_steps * step_bytes;
+    if (hp.slab_bytes < slab_bytes) {
+        HIP_TRY(hipDeviceSynchronize());
+        for (int b = 0; b < 2; ++b) {
+            for (char** p : {&hp.pin_in[b], &hp.pin_out[b]}) {
+                if (*p) (void)hipHostFree(*p);
+                *p = nullptr;
+            }
+            for (char** p : {&hp.d_in[b], &hp.d_out[b]}) {
+                if (*p) (void)hipFree(*p);
+                *p = nullptr;
+            }
+        }
+        hp.slab_bytes = 0;
+        for (int b = 0; b < 2; ++b) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hp.pin_in[b]), slab_bytes, hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hp.pin_out[b]), slab_bytes, hipHostMallocDefault));
+            HIP_TRY(hipMalloc(&hp.d_in[b], slab_bytes));
+            HIP_TRY(hipMalloc(&hp.d_out[b], slab_bytes));
+        }
+        hp.slab_bytes = slab_bytes;
+    }
+    if (!hp.s_in) {
+        HIP_TRY(hipStreamCreateWithFlags(&hp.s_in, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&hp.s_k, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&hp.s_out, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+            HIP_TRY(hipEventCreateWithFlags(&hp.ev_in[b], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&hp.ev_k[b], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&hp.ev_out[b], hipEventDisableTiming));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(nullptr));  // earlier calls of this engine on the default stream (the small-call path) are complete
+    const int n_slabs = (n_steps + slab_steps - 1) / slab_steps;
+    const int dev = e->cfg.device_id;
+    unsigned hw = std::thread::hardware_concurrency();
+    const int copy_threads = hw >= 16 ? 4 : hw >= 8 ? 2 : 1;
+    auto steps_of = [&](int i) { return i + 1 < n_slabs ? slab_steps : n_steps - i * slab_steps; };
+    std::atomic<int> staged{0}, issued{0}, drained{0}, failed{0};
+    // stager: slab i -> pin_in[i % 2] once the H2D copy of slab i - 2 has left it
+    std::thread stager([&] {
+        (void)hipSetDevice(dev);
+        for (int i = 0; i < n_slabs && !failed.load(); ++i) {
+            const int b = i & 1;
+            if (i >= 2) {
+                while (issued.load() < i - 1 && !failed.load()) std::this_thread::yield();  // (its copy has been enqueued: the event is recorded)
+                if (failed.load()) return;
+                if (hipEventSynchronize(hp.ev_in[b]) != hipSuccess) { failed.store(1); return; }
+            }
+            parallel_memcpy(hp.pin_in[b], in + (size_t)i * slab_bytes, (size_t)steps_of(i) * step_bytes, copy_threads);
+            staged.store(i + 1);
+        }
+    });
+    // drainer: pin_out[i % 2] -> the caller's array once the D2H copy of slab i has landed
+    std::thread drainer([&] {
+        (void)hipSetDevice(dev);
+        for (int i = 0; i < n_slabs; ++i) {
+            const int b = i & 1;
+            while (issued.load() < i + 1 && !failed.load()) std::this_thread::yield();
+            if (failed.load()) return;
+            if (hipEventSynchronize(hp.ev_out[b]) != hipSuccess) { failed.store(1); return; }
+            parallel_memcpy(out + (size_t)i * slab_bytes, hp.pin_out[b], (size_t)steps_of(i) * step_bytes, copy_threads);
+            drained.store(i + 1);
+        }
+    });
+    int rc = ADSP_OK;
+    hipError_t herr = hipSuccess;
+    for (int i = 0; i < n_slabs && rc == ADSP_OK && herr == hipSuccess && !failed.load(); ++i) {
+        const int b = i & 1, ns = steps_of(i);
+        const size_t bytes = (size_t)ns * step_bytes;
+        while (staged.load() < i + 1 && !failed.load()) std::this_thread::yield();
+        if (failed.load()) break;
+        // d_in[b] was read by the kernel (and the ring update) of slab i - 2; pin_out[b] / d_out[b] must have been drained of slab i - 2
+        if (i >= 2 && (herr = hipStreamWaitEvent(hp.s_in, hp.ev_k[b], 0)) != hipSuccess) break;
+        if ((herr = hipMemcpyAsync(hp.d_in[b], hp.pin_in[b], bytes, hipMemcpyHostToDevice, hp.s_in)) != hipSuccess) break;
+        if ((herr = hipEventRecord(hp.ev_in[b], hp.s_in)) != hipSuccess) break;
+        if ((herr = hipStreamWaitEvent(hp.s_k, hp.ev_in[b], 0)) != hipSuccess) break;
+        if (i >= 2 && (herr = hipStreamWaitEvent(hp.s_k, hp.ev_out[b], 0)) != hipSuccess) break;  // d_out[b]: the D2H copy of slab i - 2 is done
+        if ((rc = adsp_apply_device(e, hp.d_in[b], hp.d_out[b], ns, hp.s_k))) break;
+        if ((herr = hipEventRecord(hp.ev_k[b], hp.s_k)) != hipSuccess) break;
+        while (drained.load() < i - 1 && !failed.load()) std::this_thread::yield();  // pin_out[b] has been copied out (slab i - 2)
+        if ((herr = hipStreamWaitEvent(hp.s_out, hp.ev_k[b], 0)) != hipSuccess) break;
+        if ((herr = hipMemcpyAsync(hp.pin_out[b], hp.d_out[b], bytes, hipMemcpyDeviceToHost, hp.s_out)) != hipSuccess) break;
+        if ((herr = hipEventRecord(hp.ev_out[b], hp.s_out)) != hipSuccess) break;
+        issued.store(i + 1);
+    }
+    if (rc != ADSP_OK || herr != hipSuccess) failed.store(1);
+    stager.join();
+    drainer.join();
+    (void)hipStreamSynchronize(hp.s_in);
+    (void)hipStreamSynchronize(hp.s_k);
+    (void)hipStreamSynchronize(hp.s_out);
+    if (rc) return rc;
+    if (herr != hipSuccess) return fail(ADSP_ERR_HIP, "pipelined host call: %s", hipGetErrorString(herr));
+    if (failed.load()) return fail(ADSP_ERR_HIP, "pipelined host call: a copy stream failed: %s", hipGetErrorString(hipGetLastError()));
+    return ADSP_OK;
+}
+}  // namespace
+
 int adsp_apply_host(adsp_engine* e, const void* in, void* out, int n_steps) {
     if (!e || !in || !out) return fail(ADSP_ERR_ARG, "NULL argument");
     if (n_steps <= 0) return fail(ADSP_ERR_ARG, "n_steps must be positive");
     if (!e->have_spectrum) return fail(ADSP_ERR_STATE, "adsp_set_spectrum has not been called");
+    ADSP_NOT_RESIDENT(e);
     int rc = set_device(e);
     if (rc) return rc;
     const size_t elems = (size_t)n_steps * e->plane();
     if (elems * e->ssize() <= kHostDirectMax) return apply_host_direct(e, in, out, n_steps, elems * e->ssize());
+    // real batches: slabs through pinned staging, copies and kernels overlapped (a fused tremolo and an accumulating output keep the
+    // one-piece form: the first restarts its LFO per launch run, the second needs the caller's output on the device first)
+    if (n_steps >= 4 && elems * e->ssize() >= (16u << 20) && e->accumulate == 0 && e->epi_op != ADSP_EFFECT_TREMOLO && !getenv("ADSP_HOST_UNPIPELINED"))
+        return apply_host_pipelined(e, static_cast<const char*>(in), static_cast<char*>(out), n_steps);
     if (elems > e->stage_elems) {
         HIP_TRY(hipDeviceSynchronize());
         if (e->stage_in) (void)hipFree(e->stage_in);

@@ -170,8 +170,11 @@ class FirEngine:
         _capi.check(self._lib.adsp_set_state(self._h, _ptr(h)))
 
     # -- apply --------------------------------------------------------------------------------
-    def apply_host(self, x):
-        """x: host array [steps, C, N] (or [C, N]) of the engine's sample type -> same shape, fresh array."""
+    def apply_host(self, x, out=None):
+        """x: host array [steps, C, N] (or [C, N]) of the engine's sample type -> same shape; a fresh array like the reference's apply
+        (EffectFFTFilter.py:75), or `out` (C-contiguous, same shape and type: a gigabyte-sized batch need not be allocated and
+        page-faulted per call).  Batches beyond a few megabytes move in slabs through pinned staging, copies overlapped with the
+        kernels (adsp_apply_host)."""
         if self.sample_format != "f32" and np.asarray(x).dtype != np.int16:
             raise TypeError("this engine filters int16 PCM; pass an int16 array")
         x = np.ascontiguousarray(x, dtype=self.dtype)
@@ -180,9 +183,14 @@ class FirEngine:
             x = x[None]
         if x.ndim != 3 or x.shape[1:] != (self.channels, self.chunk_size):
             raise ValueError(f"expected [steps, {self.channels}, {self.chunk_size}], got {x.shape}")
-        out = np.empty_like(x)
-        _capi.check(self._lib.adsp_apply_host(self._h, _ptr(x), _ptr(out), x.shape[0]))
-        return out[0] if squeeze else out
+        if out is None:
+            res = np.empty_like(x)
+        else:
+            res = out[None] if squeeze and out.ndim == 2 else out
+            if res.shape != x.shape or res.dtype != x.dtype or not res.flags.c_contiguous:
+                raise ValueError("out must be a C-contiguous array of the input's shape and type")
+        _capi.check(self._lib.adsp_apply_host(self._h, _ptr(x), _ptr(res), x.shape[0]))
+        return res[0] if squeeze else res
 
     def apply_device(self, d_in, d_out, n_steps=1, stream=None):
         """Asynchronous, device-resident [n_steps, C, N] float32 buffers (torch tensors or addresses)."""

@@ -113,6 +113,7 @@ def test_upols_engine_int16_and_fused_effect(adsp):
     torch.cuda.synchronize()
     t = _exact(adsp, eng.fir, x).cpu().numpy()
     assert_parity(y.cpu().numpy(), fx.saturator(t), what="fused saturator")
+    adsp.config.initialize(44100, n)
     with pytest.raises(ValueError):
         eng.set_epilogue(adsp.CreateTremolo())
     eng.close()
@@ -135,6 +136,43 @@ def test_upols_raw_abi_refusals(adsp):
     assert lib.adsp_upols_create(ctypes.byref(cfg), spec.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)) == 0
     assert lib.adsp_upols_apply_device(h, None, None, 1, None) != 0 and lib.adsp_upols_set_epilogue(h, 5, 0.4, 1e-4, 100.0) != 0
     lib.adsp_upols_destroy(h)
+
+
+def test_large_host_batches_move_through_pipelined_pinned_staging(adsp):
+    """adsp_apply_host on a real batch (EffectFFTFilter.py:49-75 for many channels and chunks per call) - slabs through
+    double-buffered pinned staging, H2D / kernel / D2H overlapped.  The result equals the device-resident path's (every sample against
+    the float64 direct sum), slab boundaries carry the history, a second call continues the stream, int16 batches and the
+    one-piece fallback (ADSP_HOST_UNPIPELINED) agree."""
+    import torch
+    from pyaudiodsptools_amd import FirEngine, FirStream, design
+    n, C, steps = 4096, 96, 37   # 58 MB per direction: 7 slabs of whole tiles, a ragged last one
+    fir = FirStream(design.lowcut_kernel(800, 44100, n), n)
+    x = torch.empty((steps, C, n), device="cuda").uniform_(-1, 1, generator=torch.Generator(device="cuda").manual_seed(21))
+    t = _exact(adsp, fir, x).cpu().numpy()
+    xh = x.cpu().numpy()
+    scale = float(np.abs(t).max())
+    for optimize_for in ("batch", "stream"):
+        eng = FirEngine(fir, channels=C, optimize_for=optimize_for)
+        y = eng.apply_host(xh[:30])
+        out = np.empty_like(xh[30:])
+        y2 = eng.apply_host(xh[30:], out=out)   # a second call continues the stream; `out` is filled in place
+        assert y2 is out and np.abs(np.concatenate([y, y2]) - t).max() <= 1e-5 * scale, optimize_for
+        os.environ["ADSP_HOST_UNPIPELINED"] = "1"
+        try:
+            eng.reset()
+            y3 = eng.apply_host(xh)
+        finally:
+            del os.environ["ADSP_HOST_UNPIPELINED"]
+        assert np.abs(y3 - t).max() <= 1e-5 * scale
+        with pytest.raises(ValueError):
+            eng.apply_host(xh, out=np.empty((steps, C, n), np.float64))
+        eng.close()
+    pcm = torch.randint(-12000, 12000, (64, 200, n), device="cuda", dtype=torch.int16, generator=torch.Generator(device="cuda").manual_seed(22))
+    want = _exact(adsp, fir, pcm, "s16").cpu().numpy().astype(np.int32)
+    eng = FirEngine(fir, channels=200, sample_format="s16", optimize_for="batch")
+    got = eng.apply_host(pcm.cpu().numpy()).astype(np.int32)
+    assert np.abs(got - want).max() <= 1 and (got != want).mean() <= 0.01
+    eng.close()
 
 
 # ---------------------------------------------------------------------------------------------------------------------
