@@ -274,7 +274,18 @@ ADSP_API int adsp_apply_ring(adsp_engine* engine, void* d_out, void* stream);
  * per-step events above order the steps through the ring.  What changes for the caller: the outputs are NOT ordered on `stream`
  * any more - adsp_ring_join(engine, stream) makes `stream` wait for every step issued so far (call it before `stream` reads
  * d_out, or synchronise the device).  Needs ring_slots >= history_chunks + 2; depth 1 restores the default.  Measured on
- * config 2's per-chunk pattern (4096 channels x 4096 samples, one launch per chunk): 44 us per step against 48.6 on one stream. */
+ * config 2's per-chunk pattern (4096 channels x 4096 samples, one launch per chunk): 44 us per step against 48.6 on one stream.
+ * Depth 3 (round 5): the same three calls RIDE A LIVE SESSION (below) that the library starts on first use, feeds and stops by itself -
+ * one persistent launch with the history on chip instead of a launch per step (config 3, 4096 channels x 512 samples: the step a
+ * real-time caller pays drops from ~8 us to the session's ~5.6 us without a second API).  adsp_ring_acquire[_stream] returns the next
+ * slot once the session has left it (the host waits where it lags), adsp_apply_ring enqueues ONE one-lane kernel on `stream` behind the
+ * producer - it stores the step's output address and publishes the step - and returns; adsp_ring_join BLOCKS THE HOST until every step
+ * submitted so far has its outputs in memory (they are written through: any stream may read them afterwards).  Refused with
+ * ADSP_ERR_ARG where no session can hold the engine (more channel groups than the GPU keeps resident of that kernel, generic geometry,
+ * int16, fused effect): fall back to depth 2.  A session that sees no step for the time-out of adsp_live_configure (default 1 s) ends
+ * by itself and the next step starts a fresh one; any call that needs the engine in its ordinary state (adsp_apply_device, the
+ * spectrum setters, adsp_reset, a depth change ..) winds the session down first.  The outputs of step k must not be read before a
+ * join that follows its adsp_apply_ring. */
 ADSP_API int adsp_ring_set_pipeline(adsp_engine* engine, int depth);
 ADSP_API int adsp_ring_join(adsp_engine* engine, void* stream);
 /* Resident ring launches: ONE launch consumes the next n_steps ring steps, and the workgroups of step k start as soon

@@ -320,6 +320,9 @@ struct adsp_engine {
         size_t own_tw_bytes = 0, own_pair_bytes = 0, own_pair0_bytes = 0;
         int load_mode = 2;
         double timeout_ms = 1000.0;
+        bool pipeline_owned = false;            // started by adsp_apply_ring in pipeline mode 3 (the library feeds and stops it)
+        unsigned long long* d_out_table = nullptr;  // per-step output addresses (inside d_words), out_table_mask + 1 entries
+        unsigned out_table_mask = 0;
     } live;
     hipStream_t copy_stream;  // ring update of multi-step launches runs beside the kernel
     hipEvent_t ev_in_ready, ev_copy_done;
@@ -493,13 +496,28 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
+// A session started by the library itself (adsp_ring_set_pipeline(engine, 3): adsp_apply_ring rides a live session) is wound down by
+// any call that needs the engine in its ordinary state; a session the caller started (adsp_live_start) is the caller's to stop.
+namespace {
+int live_pipe_release(adsp_engine* e);
+int live_pipe_acquire(adsp_engine* e, void** d_slot);
+int live_pipe_apply(adsp_engine* e, void* d_out, hipStream_t stream);
+int live_pipe_check(adsp_engine* e);
+}
+#define ADSP_NOT_LIVE(e)                                                                                                  \
+    do {                                                                                                                  \
+        if ((e)->live.active) {                                                                                           \
+            if (!(e)->live.pipeline_owned)                                                                                \
+                return fail(ADSP_ERR_STATE, "a live session is running (adsp_live_start): call adsp_live_stop first");    \
+            const int rc_live_ = live_pipe_release(e);                                                                    \
+            if (rc_live_) return rc_live_;                                                                                \
+        }                                                                                                                 \
+    } while (0)
+
 #define ADSP_NOT_RESIDENT(e)                                                                                              \
-    if ((e)->live.active) return fail(ADSP_ERR_STATE, "a live session owns the ring (adsp_live_start): call adsp_live_stop first");  \
+    ADSP_NOT_LIVE(e);                                                                                                     \
     if ((e)->resident_mode)                                                                                                \
         return fail(ADSP_ERR_STATE, "the ring is in resident mode (adsp_ring_produce_* / adsp_apply_ring_resident): call adsp_ring_reset_order first")
-
-#define ADSP_NOT_LIVE(e) \
-    if ((e)->live.active) return fail(ADSP_ERR_STATE, "a live session is running (adsp_live_start): call adsp_live_stop first")
 
 extern "C" {
 
@@ -1327,6 +1345,7 @@ int apply_device_run(adsp_engine* e, const void* d_in, void* d_out, int n_steps,
 
 int adsp_ring_acquire(adsp_engine* e, void** d_slot) {
     if (!e || !d_slot) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (e->pipe_depth == 3) return live_pipe_acquire(e, d_slot);
     ADSP_NOT_RESIDENT(e);
     const int slot = (e->ring_pos + 1) % e->cfg.ring_slots;
     *d_slot = e->ring + (size_t)slot * e->plane_bytes();
@@ -1356,6 +1375,7 @@ int adsp_ring_reset_order(adsp_engine* e) {
 
 int adsp_ring_acquire_stream(adsp_engine* e, void** d_slot, void* stream_v) {
     if (!e || !d_slot) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (e->pipe_depth == 3) return live_pipe_acquire(e, d_slot);  // (the session's flow control is the host's: nothing to order on the stream)
     ADSP_NOT_RESIDENT(e);
     int rc = set_device(e);
     if (rc) return rc;
@@ -1367,6 +1387,7 @@ int adsp_ring_acquire_stream(adsp_engine* e, void** d_slot, void* stream_v) {
 int adsp_apply_ring(adsp_engine* e, void* d_out, void* stream_v) {
     if (!e || !d_out) return fail(ADSP_ERR_ARG, "NULL argument");
     if (!e->have_spectrum) return fail(ADSP_ERR_STATE, "adsp_set_spectrum has not been called");
+    if (e->pipe_depth == 3) return live_pipe_apply(e, d_out, (hipStream_t)stream_v);  // the step rides the library's live session
     ADSP_NOT_RESIDENT(e);
     int rc = set_device(e);
     if (rc) return rc;
@@ -1418,16 +1439,18 @@ int adsp_apply_ring(adsp_engine* e, void* d_out, void* stream_v) {
 
 int adsp_ring_set_pipeline(adsp_engine* e, int depth) {
     if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
-    if (depth < 1 || depth > 2) return fail(ADSP_ERR_ARG, "pipeline depth must be 1 (steps run on the caller's stream) or 2");
-    ADSP_NOT_RESIDENT(e);
+    if (depth < 1 || depth > 3)
+        return fail(ADSP_ERR_ARG, "pipeline depth must be 1 (steps run on the caller's stream), 2 (on the library's two streams in turn) or 3 (ride a live session)");
+    ADSP_NOT_RESIDENT(e);  // (also winds down a session the previous depth 3 owned)
     int rc = set_device(e);
     if (rc) return rc;
     if (depth > 1 && e->cfg.ring_slots < e->cfg.history_chunks + 2)
         return fail(ADSP_ERR_ARG, "pipelined steps need ring_slots >= history_chunks + 2 (%d): with fewer the producer of step k + 1 waits for the kernel of step k",
                     e->cfg.history_chunks + 2);
+    if (depth == 3 && (rc = live_pipe_check(e))) return rc;  // ADSP_ERR_ARG where no session can run this engine: the caller falls back to depth 2
     HIP_TRY(hipDeviceSynchronize());  // a mode switch: nothing of the ring is in flight
     ring_forget_steps(e);
-    for (int i = 0; i < depth && depth > 1; ++i)
+    for (int i = 0; i < 2 && depth == 2; ++i)
         if (!e->pipe_stream[i]) HIP_TRY(hipStreamCreateWithFlags(&e->pipe_stream[i], hipStreamNonBlocking));
     e->pipe_depth = depth;
     return ADSP_OK;
@@ -1437,6 +1460,13 @@ int adsp_ring_join(adsp_engine* e, void* stream_v) {
     if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
     int rc = set_device(e);
     if (rc) return rc;
+    if (e->pipe_depth == 3) {
+        // the steps ride a session: the HOST waits until every step submitted so far has its outputs in memory (the publications sit on
+        // the caller's stream behind its producers; the session writes through, so any stream may read the outputs afterwards)
+        adsp_engine::Live& L = e->live;
+        if (!L.active || !L.pipeline_owned || L.published == 0) return ADSP_OK;
+        return adsp_live_wait(e, L.published, 20000.0);
+    }
     if (e->pipe_depth < 2) return ADSP_OK;  // steps already run on the caller's stream
     for (int i = 0; i < e->pipe_depth; ++i) {
         hipEvent_t& ev = e->pipe_ev[e->pipe_ev_next++ % 8];
@@ -1588,11 +1618,21 @@ int adsp_live_configure(adsp_engine* e, double step_timeout_ms, int load_mode) {
     return ADSP_OK;
 }
 
+namespace {
+int live_start_impl(adsp_engine* e, void* d_out, int out_slots, unsigned max_steps, void* stream_v, bool with_out_table);
+}
+
 int adsp_live_start(adsp_engine* e, void* d_out, int out_slots, unsigned max_steps, void* stream_v) {
     if (!e || !d_out) return fail(ADSP_ERR_ARG, "NULL argument");
     if (!e->have_spectrum) return fail(ADSP_ERR_STATE, "adsp_set_spectrum has not been called");
     if (out_slots < 1 || max_steps < 1) return fail(ADSP_ERR_ARG, "out_slots and max_steps must be positive");
     ADSP_NOT_RESIDENT(e);
+    if (e->pipe_depth == 3) return fail(ADSP_ERR_STATE, "ring steps ride a live session of the library's own (adsp_ring_set_pipeline(engine, 3)): switch to depth 1 first");
+    return live_start_impl(e, d_out, out_slots, max_steps, stream_v, false);
+}
+
+namespace {
+int live_start_impl(adsp_engine* e, void* d_out, int out_slots, unsigned max_steps, void* stream_v, bool with_out_table) {
     if (e->multi_stream) return fail(ADSP_ERR_STATE, "ring steps are in flight on several streams: call adsp_ring_reset_order first");
     int rc = set_device(e);
     if (rc) return rc;
@@ -1624,7 +1664,7 @@ int adsp_live_start(adsp_engine* e, void* d_out, int out_slots, unsigned max_ste
     size_t arrival_slots = 1024;
     while (arrival_slots <= (size_t)c.ring_slots) arrival_slots *= 2;
     const size_t n_pad = ((size_t)ncg + 255) & ~(size_t)255;
-    const size_t n_words = 4 + n_pad + arrival_slots * 256;  // sixteen 64-byte shards per slot
+    const size_t n_words = 4 + n_pad + arrival_slots * 256 + arrival_slots * 2;  // sixteen 64-byte shards per slot; then one 8-byte output address per slot
     if (L.d_words_n < n_words) {
         if (L.d_words) (void)hipFree(L.d_words);
         L.d_words = nullptr;
@@ -1733,6 +1773,10 @@ int adsp_live_start(adsp_engine* e, void* d_out, int out_slots, unsigned max_ste
     la.load_mode = L.load_mode;
     la.trace = nullptr;
     la.relay_mode = getenv("ADSP_LIVE_RELAY_OFF") ? 1 : 0;
+    L.d_out_table = reinterpret_cast<unsigned long long*>(L.d_words + 4 + n_pad + arrival_slots * 256);  // (8-byte aligned: every term is a multiple of 4 words)
+    L.out_table_mask = (unsigned)arrival_slots - 1u;
+    la.out_table = with_out_table ? L.d_out_table : nullptr;
+    la.out_table_mask = L.out_table_mask;
     if (getenv("ADSP_LIVE_TRACE")) {
         if (!L.trace) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&L.trace), 64 * 8 * sizeof(unsigned long long), hipHostMallocMapped));
         memset(L.trace, 0, 64 * 8 * sizeof(unsigned long long));
@@ -1760,6 +1804,7 @@ int adsp_live_start(adsp_engine* e, void* d_out, int out_slots, unsigned max_ste
         e->timed.push_back(ev);
     }
     L.active = true;
+    L.pipeline_owned = false;
     L.plan = lp;
     L.published = L.pending = 0;
     L.max_steps = max_steps;
@@ -1768,6 +1813,7 @@ int adsp_live_start(adsp_engine* e, void* d_out, int out_slots, unsigned max_ste
     L.stream = stream;
     return ADSP_OK;
 }
+}  // namespace
 
 int adsp_live_slot(adsp_engine* e, void** d_slot) {
     if (!e || !d_slot) return fail(ADSP_ERR_ARG, "NULL argument");
@@ -1872,10 +1918,12 @@ int adsp_live_device_words(adsp_engine* e, unsigned** d_seq, unsigned** d_done) 
     return ADSP_OK;
 }
 
-int adsp_live_stop(adsp_engine* e, unsigned* steps_consumed) {
-    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+namespace {
+// Ends the session (once every published step is consumed), synchronises its stream and moves the engine's ring on by the steps
+// EVERY channel group consumed.  idle_timeout_ok: a session that ended by itself because no step arrived for the configured time-out
+// - every workgroup then stands at the last published step - is a clean end, not an error (sessions the pipeline owns).
+int live_finish(adsp_engine* e, unsigned* steps_consumed, bool idle_timeout_ok) {
     adsp_engine::Live& L = e->live;
-    if (!L.active) return fail(ADSP_ERR_STATE, "no live session (adsp_live_start)");
     int rc = set_device(e);
     if (rc) return rc;
     host_word_store(L.h_words + 2, 1u);
@@ -1884,7 +1932,7 @@ int adsp_live_stop(adsp_engine* e, unsigned* steps_consumed) {
     HIP_TRY(hipMemcpy(w.data(), L.d_words, w.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
     unsigned done = 0xffffffffu;
     for (int i = 0; i < L.ncg; ++i) done = w[4 + i] < done ? w[4 + i] : done;
-    const bool timed_out = w[3] != 0;
+    bool timed_out = w[3] != 0;
     if (getenv("ADSP_DEBUG")) {
         fprintf(stderr, "libadsp live_stop: seq %u done %u stop %u fail %u | host_seq %u host_done %u host_stop %u | published %u | progress:", w[0], w[1], w[2],
                 w[3], L.h_words[0], L.h_words[kLiveGpuWords], L.h_words[2], L.published);
@@ -1918,6 +1966,7 @@ int adsp_live_stop(adsp_engine* e, unsigned* steps_consumed) {
                     (seg[0] + seg[1] + seg[2] + seg[3] + seg[4] + seg[5]) / n);
     }
     L.active = false;
+    L.pipeline_owned = false;
     // the ring moves on by the steps EVERY channel group consumed (after a time-out some may be further: adsp_reset then)
     const int S = e->cfg.ring_slots;
     e->ring_pos = (int)(((long long)e->ring_pos + done) % S);
@@ -1925,9 +1974,87 @@ int adsp_live_stop(adsp_engine* e, unsigned* steps_consumed) {
     e->have_last_stream = true;
     e->last_stream = L.stream;
     if (steps_consumed) *steps_consumed = done;
+    if (timed_out && idle_timeout_ok && done == L.published) timed_out = false;  // nothing was pending: every workgroup stands at the same step
     if (timed_out) return fail(ADSP_ERR_STATE, "live session: a workgroup gave up waiting for step %u after %.0f ms (adsp_live_configure); "
                                "the engine's history is undefined: adsp_reset", done, L.timeout_ms);
     return ADSP_OK;
+}
+
+// ---- ring steps riding a session (adsp_ring_set_pipeline(engine, 3)) ------------------------------------------------------------
+int live_pipe_release(adsp_engine* e) { return live_finish(e, nullptr, true); }
+
+// can a session run this engine at all?  (the plan exists and every workgroup is resident at once: what adsp_live_start checks)
+int live_pipe_check(adsp_engine* e) {
+    const adsp::LivePlanInfo* lp = nullptr;
+    int rc = live_find_plan(e, &lp);
+    if (rc) return rc;
+    const int ncg = (e->cfg.n_channels + lp->CPB - 1) / lp->CPB;
+    int per_cu = 0, cus = 0;
+    HIP_TRY(lp->capacity(&per_cu));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->cfg.device_id));
+    const long long room = (long long)(per_cu > 1 ? per_cu - 1 : per_cu) * cus;
+    if ((long long)ncg + 2 > room)
+        return fail(ADSP_ERR_ARG, "a live session needs all %d workgroups resident at once, this device holds %lld of this kernel: ring steps of this engine "
+                    "cannot ride a session (use pipeline depth 2)", ncg + 2, room);
+    return ADSP_OK;
+}
+
+// a running session of the pipeline's own: started on first use, restarted when the previous one has ended by itself (idle time-out)
+int live_pipe_ensure(adsp_engine* e) {
+    adsp_engine::Live& L = e->live;
+    if (L.active && !L.pipeline_owned) return fail(ADSP_ERR_STATE, "a live session started with adsp_live_start is running: adsp_live_stop first");
+    if (L.active) {
+        if (host_word_load(L.h_words + kLiveGpuWords + 6) == 0 && L.published + 1u < L.max_steps) return ADSP_OK;  // (word 6: the relay's exit reason)
+        const int rc = live_finish(e, nullptr, true);
+        if (rc) return rc;
+    }
+    if (!e->have_spectrum) return fail(ADSP_ERR_STATE, "adsp_set_spectrum has not been called");
+    if (e->resident_mode) return fail(ADSP_ERR_STATE, "the ring is in resident mode: call adsp_ring_reset_order first");
+    if (e->multi_stream) return fail(ADSP_ERR_STATE, "ring steps are in flight on several streams: call adsp_ring_reset_order first");
+    int rc = set_device(e);
+    if (rc) return rc;
+    if ((rc = live_start_impl(e, e->ring /* (unused: every step names its own output) */, 1, 0x7fffff00u, nullptr, true))) return rc;
+    L.pipeline_owned = true;
+    return ADSP_OK;
+}
+
+// step q's ring slot may be refilled once the session is past step q - (ring_slots - history): wait for that (the host spins on a mapped word)
+int live_pipe_room(adsp_engine* e, unsigned q) {
+    adsp_engine::Live& L = e->live;
+    const int usable = e->cfg.ring_slots - e->cfg.history_chunks;
+    if ((long long)q - usable + 1 > (long long)host_word_load(L.h_words + kLiveGpuWords)) return adsp_live_wait(e, (unsigned)(q - usable + 1), 20000.0);
+    return ADSP_OK;
+}
+
+int live_pipe_acquire(adsp_engine* e, void** d_slot) {
+    int rc = live_pipe_ensure(e);
+    if (rc) return rc;
+    adsp_engine::Live& L = e->live;
+    const unsigned q = L.published;  // the next step (acquiring twice returns the same slot, like the other pipeline depths)
+    if ((rc = live_pipe_room(e, q))) return rc;
+    *d_slot = e->ring + (size_t)(((long long)e->ring_pos + 1 + q) % e->cfg.ring_slots) * e->plane_bytes();
+    return ADSP_OK;
+}
+
+int live_pipe_apply(adsp_engine* e, void* d_out, hipStream_t stream) {
+    int rc = live_pipe_ensure(e);
+    if (rc) return rc;
+    adsp_engine::Live& L = e->live;
+    const unsigned q = L.published;
+    if ((rc = live_pipe_room(e, q))) return rc;  // (a caller that never acquired: the producer is somebody else's business, the ring's is ours)
+    // behind whatever filled the slot on `stream`: the step's output address, then the publication
+    HIP_TRY(adsp::live_publish_out(L.d_words, q + 1u, L.d_out_table + (q & L.out_table_mask), d_out, stream));
+    L.published = q + 1u;
+    return ADSP_OK;
+}
+}  // namespace
+
+int adsp_live_stop(adsp_engine* e, unsigned* steps_consumed) {
+    if (!e) return fail(ADSP_ERR_ARG, "NULL engine");
+    adsp_engine::Live& L = e->live;
+    if (!L.active) return fail(ADSP_ERR_STATE, "no live session (adsp_live_start)");
+    if (L.pipeline_owned) return fail(ADSP_ERR_STATE, "this session belongs to the ring pipeline (adsp_ring_set_pipeline(engine, 3)): switch the depth to end it");
+    return live_finish(e, steps_consumed, false);
 }
 
 
@@ -2015,6 +2142,61 @@ void parallel_memcpy(char* dst, const char* src, size_t bytes, int threads) {
     for (auto& th : pool) th.join();
 }
 
+// The same slab pipeline without pinned staging of the library's own (ADSP_HOST_STAGING=direct): a copy-in thread and a copy-out thread
+// give the caller's pageable memory to hipMemcpyAsync slab by slab on their own streams; this thread launches the kernels.
+int apply_host_direct_slabs(adsp_engine* e, const char* in, char* out, int n_steps, int slab_steps, int n_slabs) {
+    adsp_engine::HostPipe& hp = e->hp;
+    const size_t step_bytes = e->plane_bytes(), slab_bytes = (size_t)slab_steps * step_bytes;
+    const int dev = e->cfg.device_id;
+    auto steps_of = [&](int i) { return i + 1 < n_slabs ? slab_steps : n_steps - i * slab_steps; };
+    std::atomic<int> staged{0}, issued{0}, drained{0}, failed{0};
+    std::thread stager([&] {
+        (void)hipSetDevice(dev);
+        for (int i = 0; i < n_slabs && !failed.load(); ++i) {
+            const int b = i & 1;
+            if (i >= 2) {  // d_in[b] was read by the kernel (and the ring update) of slab i - 2
+                while (issued.load() < i - 1 && !failed.load()) std::this_thread::yield();
+                if (failed.load()) return;
+                if (hipEventSynchronize(hp.ev_k[b]) != hipSuccess) { failed.store(1); return; }
+            }
+            if (hipMemcpyAsync(hp.d_in[b], in + (size_t)i * slab_bytes, (size_t)steps_of(i) * step_bytes, hipMemcpyHostToDevice, hp.s_in) != hipSuccess ||
+                hipStreamSynchronize(hp.s_in) != hipSuccess) { failed.store(1); return; }
+            staged.store(i + 1);
+        }
+    });
+    std::thread drainer([&] {
+        (void)hipSetDevice(dev);
+        for (int i = 0; i < n_slabs; ++i) {
+            const int b = i & 1;
+            while (issued.load() < i + 1 && !failed.load()) std::this_thread::yield();
+            if (failed.load()) return;
+            if (hipStreamWaitEvent(hp.s_out, hp.ev_k[b], 0) != hipSuccess ||
+                hipMemcpyAsync(out + (size_t)i * slab_bytes, hp.d_out[b], (size_t)steps_of(i) * step_bytes, hipMemcpyDeviceToHost, hp.s_out) != hipSuccess ||
+                hipStreamSynchronize(hp.s_out) != hipSuccess) { failed.store(1); return; }
+            drained.store(i + 1);
+        }
+    });
+    int rc = ADSP_OK;
+    hipError_t herr = hipSuccess;
+    for (int i = 0; i < n_slabs && !failed.load(); ++i) {
+        const int b = i & 1;
+        while (staged.load() < i + 1 && !failed.load()) std::this_thread::yield();  // (the copy-in thread synchronised its stream: the data is there)
+        while (drained.load() < i - 1 && !failed.load()) std::this_thread::yield();  // d_out[b] has been copied out (slab i - 2)
+        if (failed.load()) break;
+        if ((rc = adsp_apply_device(e, hp.d_in[b], hp.d_out[b], steps_of(i), hp.s_k))) break;
+        if ((herr = hipEventRecord(hp.ev_k[b], hp.s_k)) != hipSuccess) break;
+        issued.store(i + 1);
+    }
+    if (rc != ADSP_OK || herr != hipSuccess) failed.store(1);
+    stager.join();
+    drainer.join();
+    (void)hipStreamSynchronize(hp.s_k);
+    if (rc) return rc;
+    if (herr != hipSuccess) return fail(ADSP_ERR_HIP, "pipelined host call: %s", hipGetErrorString(herr));
+    if (failed.load()) return fail(ADSP_ERR_HIP, "pipelined host call: a copy failed: %s", hipGetErrorString(hipGetLastError()));
+    return ADSP_OK;
+}
+
 constexpr size_t kPipeSlabTarget = 48u << 20;  // bytes per slab and direction: four pinned + four device buffers of this size per engine
 
 // Large host batches (the numpy API on a real batch: WavBank.process, apply_batch - EffectFFTFilter.py:49-75 for C channels and many
@@ -2036,7 +2218,11 @@ int apply_host_pipelined(adsp_engine* e, const char* in, char* out, int n_steps)
         if (slab_steps >= tile_steps) slab_steps = slab_steps / tile_steps * tile_steps;
     }
     const size_t slab_bytes = (size_t)slab_steps * step_bytes;
-    if (hp.slab_bytes < slab_bytes) {
+    // ADSP_HOST_STAGING=direct (tuning A/B): no pinned staging of the library's own - the copy threads hand the caller's pageable memory
+    // to hipMemcpyAsync slab by slab (the runtime stages it itself), still overlapped with the kernels and with each other
+    const char* mode = getenv("ADSP_HOST_STAGING");
+    const bool direct = mode && strcmp(mode, "direct") == 0;
+    if (hp.slab_bytes < slab_bytes || (!direct && !hp.pin_in[0])) {
         HIP_TRY(hipDeviceSynchronize());
         for (int b = 0; b < 2; ++b) {
             for (char** p : {&hp.pin_in[b], &hp.pin_out[b]}) {
@@ -2050,8 +2236,10 @@ int apply_host_pipelined(adsp_engine* e, const char* in, char* out, int n_steps)
         }
         hp.slab_bytes = 0;
         for (int b = 0; b < 2; ++b) {
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hp.pin_in[b]), slab_bytes, hipHostMallocDefault));
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hp.pin_out[b]), slab_bytes, hipHostMallocDefault));
+            if (!direct) {
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hp.pin_in[b]), slab_bytes, hipHostMallocDefault));
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hp.pin_out[b]), slab_bytes, hipHostMallocDefault));
+            }
             HIP_TRY(hipMalloc(&hp.d_in[b], slab_bytes));
             HIP_TRY(hipMalloc(&hp.d_out[b], slab_bytes));
         }
@@ -2069,9 +2257,11 @@ int apply_host_pipelined(adsp_engine* e, const char* in, char* out, int n_steps)
     }
     HIP_TRY(hipStreamSynchronize(nullptr));  // earlier calls of this engine on the default stream (the small-call path) are complete
     const int n_slabs = (n_steps + slab_steps - 1) / slab_steps;
+    if (direct) return apply_host_direct_slabs(e, in, out, n_steps, slab_steps, n_slabs);
     const int dev = e->cfg.device_id;
     unsigned hw = std::thread::hardware_concurrency();
-    const int copy_threads = hw >= 16 ? 4 : hw >= 8 ? 2 : 1;
+    int copy_threads = hw >= 16 ? 4 : hw >= 8 ? 2 : 1;
+    if (const char* t = getenv("ADSP_HOST_COPY_THREADS")) copy_threads = atoi(t) > 0 && atoi(t) <= 32 ? atoi(t) : copy_threads;  // (tuning)
     auto steps_of = [&](int i) { return i + 1 < n_slabs ? slab_steps : n_steps - i * slab_steps; };
     std::atomic<int> staged{0}, issued{0}, drained{0}, failed{0};
     // stager: slab i -> pin_in[i % 2] once the H2D copy of slab i - 2 has left it

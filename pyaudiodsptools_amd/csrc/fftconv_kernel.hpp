@@ -142,6 +142,11 @@ struct LiveArgs {
     unsigned trace_first;
     int trace_wg;
     int relay_mode;                // tuning: 1 = the relay leaves at once (publications must then come from the device side)
+    // per-step output pointers (round 5: adsp_apply_ring riding a session, adsp_ring_set_pipeline(engine, 3)): entry s & out_table_mask holds
+    // the device address the N outputs per channel of step s go to ([C][N], like one slot of `out`); the publisher writes it BEFORE it
+    // bumps the sequence word.  nullptr: the output ring `out` above.
+    const unsigned long long* out_table;
+    unsigned out_table_mask;
 };
 
 #define ADSP_F64 0

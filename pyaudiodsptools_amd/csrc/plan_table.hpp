@@ -84,6 +84,7 @@ const PlanInfo* plans_f32_epi(int* count);  // same list, kernels with the fused
 const PlanInfo* variants_f32(int* count);  // A/B alternatives, ADSP_PLAN_VARIANT=<n>
 const LivePlanInfo* live_plans(int* count);  // plans_live.hip
 hipError_t live_publish(unsigned* seq, unsigned value, hipStream_t s);
+hipError_t live_publish_out(unsigned* seq, unsigned value, unsigned long long* entry, void* d_out, hipStream_t s);  // + the step's output address
 const PlanInfo* plans_s16_f64(int* count);  // int16 samples, float64 arithmetic (namespace adsp::f64 kernels): plans_s16_f64.hip
 
 }  // namespace adsp

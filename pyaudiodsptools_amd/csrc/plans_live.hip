@@ -11,6 +11,13 @@ __global__ void live_publish_kernel(unsigned* seq, unsigned value) {
     __hip_atomic_fetch_max(seq, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ... and the same with the step's output address (sessions fed by adsp_apply_ring): the table entry first, then the publication with
+// release semantics at system scope - a worker that has seen the publication reads the entry behind it
+__global__ void live_publish_out_kernel(unsigned* seq, unsigned value, unsigned long long* entry, unsigned long long d_out) {
+    __hip_atomic_store(entry, d_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_fetch_max(seq, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // exchange buffers + the pass twiddles, which a session keeps in LDS when they fit beside eight workgroups per CU; the plan with one
 // wave per channel (17 workgroups per CU) keeps rows 0 of the tables only and forms the other powers in registers
 template <class PL, int CPB>
@@ -65,5 +72,10 @@ const adsp::LivePlanInfo* adsp::live_plans(int* count) {
 
 hipError_t adsp::live_publish(unsigned* seq, unsigned value, hipStream_t s) {
     hipLaunchKernelGGL(live_publish_kernel, dim3(1), dim3(1), 0, s, seq, value);
+    return hipGetLastError();
+}
+
+hipError_t adsp::live_publish_out(unsigned* seq, unsigned value, unsigned long long* entry, void* d_out, hipStream_t s) {
+    hipLaunchKernelGGL(live_publish_out_kernel, dim3(1), dim3(1), 0, s, seq, value, entry, reinterpret_cast<unsigned long long>(d_out));
     return hipGetLastError();
 }

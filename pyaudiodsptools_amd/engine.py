@@ -208,9 +208,19 @@ class FirEngine:
         return p.value
 
     def ring_set_pipeline(self, depth=2):
-        """depth 2: the library runs ring step k on its own stream k % 2 (consecutive launches overlap); the caller keeps one
-        stream for its producers and calls ring_join(stream) before that stream reads outputs.  depth 1: the default."""
+        """depth 2: the library runs ring step k on its own stream k % 2 (consecutive launches overlap); depth 3: the steps RIDE A LIVE
+        SESSION the library starts, feeds and stops by itself (one persistent launch, history on chip: adsp_live_*) - available where a
+        session can hold the engine (AdspError otherwise); "auto": 3 where possible, else 2.  The caller keeps one stream for its
+        producers (ring_acquire(stream) -> fill the slot on that stream -> apply_ring(out, stream)) and calls ring_join(stream) before
+        anything reads outputs.  depth 1: the default (every step a launch on the caller's stream).  Returns the depth in force."""
+        if depth == "auto":
+            try:
+                _capi.check(self._lib.adsp_ring_set_pipeline(self._h, 3))
+                return 3
+            except _capi.AdspError:
+                depth = 2
         _capi.check(self._lib.adsp_ring_set_pipeline(self._h, int(depth)))
+        return int(depth)
 
     def ring_join(self, stream=None):
         _capi.check(self._lib.adsp_ring_join(self._h, _ptr(stream)))

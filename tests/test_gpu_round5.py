@@ -265,3 +265,71 @@ def test_filtered_signal_and_original_signal_mirror_the_reference(adsp):
     eq.apply(x[:n])
     eq.apply(x[n:])
     assert np.array_equal(eq.original_signal, np.concatenate([np.zeros(n), x[:n], x[n:]])) and not eq.filtered_signal.any()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 5. Ring steps riding a live session (adsp_ring_set_pipeline(engine, 3))
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,kind,channels,slots", [(512, "eq", 4096, 40), (512, "lowcut", 70, 9), (2048, "lowcut", 33, 6), (128, "highcut", 1000, 12)])
+def test_ring_steps_ride_a_live_session_with_a_real_producer(adsp, n, kind, channels, slots):
+    """the per-step entry points (adsp_ring_acquire_stream -> producer on the caller's stream -> adsp_apply_ring ->
+    adsp_ring_join; the reference's call pattern Example3.py:20-24, EffectEQ3BandFFT.py:156-211 per chunk) at pipeline depth 3: every
+    step names its own output buffer, a real copy fills each slot on the caller's stream, the outputs equal the float64 direct sum;
+    an ordinary call in between winds the session down and the next step starts a new one; an idle session ends by its time-out and
+    is restarted; the depth falls back where no session can hold the engine."""
+    import ctypes
+    import time
+    import torch
+    from pyaudiodsptools_amd import FirEngine, FirStream, design, _capi
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    fs = 44100
+    taps = {"eq": lambda: design.eq3_composite(100, 2, 700, -4, 8000, 5, fs, n), "lowcut": lambda: design.lowcut_kernel(300, fs, n),
+            "highcut": lambda: design.highcut_kernel(5000, fs, n)}[kind]()
+    fir = FirStream(taps, n)
+    steps = 3 * slots + 5   # several ring laps
+    x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=torch.Generator(device="cuda").manual_seed(n + channels))
+    t = _exact(adsp, fir, x)
+    scale = float(t.abs().max())
+    eng = FirEngine(fir, channels=channels, ring_slots=slots, optimize_for="stream")
+    eng.live_configure(step_timeout_ms=300.0)
+    assert eng.ring_set_pipeline("auto") == 3
+    y = torch.full_like(x, 7.0)
+    user = torch.cuda.Stream()
+    sp = user.cuda_stream
+    plane = channels * n * 4
+
+    def feed(k0, k1):
+        for k in range(k0, k1):
+            slot = eng.ring_acquire(sp)
+            assert hip.hipMemcpyAsync(slot, x[k].data_ptr(), plane, 3, sp) == 0   # the producer: a device copy on the caller's stream
+            eng.apply_ring(y[k], sp)
+        eng.ring_join(sp)
+    a, b = steps // 3, 2 * steps // 3
+    feed(0, a)
+    assert float((y[:a] - t[:a]).abs().max()) <= 1e-5 * scale and float(y[a:].min()) == 7.0
+    # an ordinary launch in between: the session is wound down, the stream continues, the next ring step starts a new session
+    eng.apply_device(x[a], y[a], 1, sp)
+    user.synchronize()
+    feed(a + 1, b)
+    time.sleep(0.7)            # idle beyond the time-out: the session ends by itself ...
+    feed(b, steps)             # ... and the next step starts a fresh one on the same history
+    user.synchronize()
+    assert float((y - t).abs().max()) <= 1e-5 * scale
+    assert eng.ring_set_pipeline(1) == 1   # (winds the session down)
+    eng.close()
+
+
+def test_ring_pipeline_depth_3_is_refused_where_no_session_fits(adsp):
+    from pyaudiodsptools_amd import FirEngine, FirStream, design, _capi
+    n = 4096
+    fir = FirStream(design.lowcut_kernel(800, 44100, n), n)
+    eng = FirEngine(fir, channels=4096, ring_slots=4, optimize_for="stream")   # config 2: 4096 workgroups of 256 threads are not co-resident
+    with pytest.raises(_capi.AdspError):
+        eng.ring_set_pipeline(3)
+    assert eng.ring_set_pipeline("auto") == 2
+    eng.close()
+    eng = FirEngine(fir, channels=8, ring_slots=3, optimize_for="stream")      # history + 1 slots: no pipelining of any depth
+    with pytest.raises(_capi.AdspError):
+        eng.ring_set_pipeline(3)
+    eng.close()
