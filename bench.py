@@ -715,8 +715,8 @@ def host_batch_figures(dev, gib=1.0, files=256, seconds_per_file=10):
     """The numpy API on REAL batches (host arrays in, host arrays out - the reference's contract, EffectFFTFilter.py:49-75, for many
     channels and chunks per call): FirEngine.apply_host on a `gib` GiB float32 batch (4096 channels x 4096 samples x 16 chunks) and
     WavBank.process on `files` mono 16-bit WAV files, against the PCIe Gen5 x16 link (63 GB/s per direction, MI355X_MICROARCH.md).
-    Large host calls move in slabs through double-buffered pinned staging, H2D / kernel / D2H overlapped (adsp_apply_host); the
-    one-piece form it replaced (pageable hipMemcpy in, kernel, hipMemcpy out) is timed beside it (ADSP_HOST_UNPIPELINED=1)."""
+    Large host calls move in slabs, H2D / kernel / D2H overlapped on three streams (adsp_apply_host); the one-piece form it replaced
+    (pageable hipMemcpy in, kernel, hipMemcpy out) is timed beside it (ADSP_HOST_UNPIPELINED=1)."""
     import tempfile
     import torch
     import wave
@@ -759,8 +759,8 @@ def host_batch_figures(dev, gib=1.0, files=256, seconds_per_file=10):
                                "frac_of_link": round(nbytes / t_pipe / 1e9 / 63.0, 3), "msamples_s": round(steps * C * n / t_pipe / 1e6, 1),
                                "unpipelined_seconds": round(t_plain, 4), "unpipelined_gb_per_s_each_direction": round(nbytes / t_plain / 1e9, 2),
                                "max_rel_err_vs_device_path": float(f"{err:.3e}"),
-                               "note": "FirEngine.apply_host(x, out=out), out reused; median of 3; the host side (pageable -> pinned copies by a few threads) and "
-                                       "the link bound it, never the kernel"}}
+                               "note": "FirEngine.apply_host(x, out=out), out reused; median of 3; slabs of the caller's pageable arrays handed to hipMemcpyAsync by a "
+                                       "copy-in and a copy-out thread beside the kernels; the host's memory system and the link bound it, never the kernel"}}
     del eng, x, out
     # WavBank.process: many 16-bit WAV files -> one int16 batch -> one host call -> int16 per file (Example1 / Example2 for many files)
     config.initialize(fs, n)

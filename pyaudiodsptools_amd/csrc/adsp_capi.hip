@@ -471,7 +471,19 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
             a.nt_hi = pl.P / 2 - overlap;
         }
     }
-    const long long grid = (long long)((a.ncg + 7) / 8) * 8 * (resident ? (a.nblk + a.step_tile - 1) / a.step_tile * a.step_tile : a.nblk);  // resident: whole step tiles
+    a.blk_iters = 1;
+    a.self = nullptr;
+    if (getenv("ADSP_PERSIST_BUILD")) {  // tuning: a library whose kernels were built with -DADSP_PERSIST=1 (they read their arguments from a.self)
+        const char* bi = getenv("ADSP_BLK_ITERS");
+        a.blk_iters = (bi && !resident && !e->generic && atoi(bi) > 1) ? atoi(bi) : 1;
+        static void* d_args[64] = {nullptr};  // a small ring of argument copies: launches in flight never share one
+        static unsigned d_next = 0;
+        void*& slot = d_args[d_next++ % 64];
+        if (!slot) HIP_TRY(hipMalloc(&slot, sizeof a));
+        a.self = slot;
+    }
+    const long long grid = (long long)((a.ncg + 7) / 8) * 8 *
+                           (resident ? (a.nblk + a.step_tile - 1) / a.step_tile * a.step_tile : (a.nblk + a.blk_iters - 1) / a.blk_iters);  // resident: whole step tiles
     if (grid > 0x7fffffffLL) return fail(ADSP_ERR_ARG, "launch too large (%lld workgroups)", grid);
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     if (e->timing) {
@@ -484,6 +496,7 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
         }
         HIP_TRY(hipEventRecord(ev.first, stream));
     }
+    if (a.self) HIP_TRY(hipMemcpyAsync(const_cast<void*>(a.self), &a, sizeof a, hipMemcpyHostToDevice, stream));  // (tuning builds; `a` is copied by the call)
     HIP_TRY(e->unaligned ? pl.launch_unaligned(a, (int)grid, stream) : e->generic ? pl.launch_generic(a, (int)grid, stream) : pl.launch(a, (int)grid, stream));
     if (e->want_kernel_event) HIP_TRY(hipEventRecord(e->ev_kernel, stream));
     if (e->timing) {
@@ -2142,8 +2155,8 @@ void parallel_memcpy(char* dst, const char* src, size_t bytes, int threads) {
     for (auto& th : pool) th.join();
 }
 
-// The same slab pipeline without pinned staging of the library's own (ADSP_HOST_STAGING=direct): a copy-in thread and a copy-out thread
-// give the caller's pageable memory to hipMemcpyAsync slab by slab on their own streams; this thread launches the kernels.
+// The slab pipeline in its default form, without pinned staging of the library's own: a copy-in thread and a copy-out thread give the
+// caller's pageable memory to hipMemcpyAsync slab by slab on their own streams; this thread launches the kernels.
 int apply_host_direct_slabs(adsp_engine* e, const char* in, char* out, int n_steps, int slab_steps, int n_slabs) {
     adsp_engine::HostPipe& hp = e->hp;
     const size_t step_bytes = e->plane_bytes(), slab_bytes = (size_t)slab_steps * step_bytes;
@@ -2200,10 +2213,11 @@ int apply_host_direct_slabs(adsp_engine* e, const char* in, char* out, int n_ste
 constexpr size_t kPipeSlabTarget = 48u << 20;  // bytes per slab and direction: four pinned + four device buffers of this size per engine
 
 // Large host batches (the numpy API on a real batch: WavBank.process, apply_batch - EffectFFTFilter.py:49-75 for C channels and many
-// chunks at once): slabs of whole steps through double-buffered pinned staging.  Three threads of control on the host - a stager that
-// fills pin_in, this thread that enqueues copies and launches, a drainer that empties pin_out - and three streams on the device, so
-// that the H2D copy of slab i + 1, the kernel of slab i and the D2H copy of slab i - 1 overlap, and so do the host's own copies in
-// and out of pinned memory.  Steps are independent through the engine's history ring, so a slab is just a shorter call.
+// chunks at once): slabs of whole steps, double-buffered on the device.  Three threads of control on the host - one that copies slabs
+// in, this thread that launches, one that copies slabs out - and three streams on the device, so that the H2D copy of slab i + 1, the
+// kernel of slab i and the D2H copy of slab i - 1 overlap.  Steps are independent through the engine's history ring, so a slab is just
+// a shorter call.  (ADSP_HOST_STAGING=pinned: the same through pinned staging buffers of the library's own, filled and emptied by a few
+// host threads - kept for A/B, slower on the boxes measured.)
 int apply_host_pipelined(adsp_engine* e, const char* in, char* out, int n_steps) {
     adsp_engine::HostPipe& hp = e->hp;
     const size_t step_bytes = e->plane_bytes();
@@ -2218,10 +2232,14 @@ int apply_host_pipelined(adsp_engine* e, const char* in, char* out, int n_steps)
         if (slab_steps >= tile_steps) slab_steps = slab_steps / tile_steps * tile_steps;
     }
     const size_t slab_bytes = (size_t)slab_steps * step_bytes;
-    // ADSP_HOST_STAGING=direct (tuning A/B): no pinned staging of the library's own - the copy threads hand the caller's pageable memory
-    // to hipMemcpyAsync slab by slab (the runtime stages it itself), still overlapped with the kernels and with each other
+    // default: no pinned staging of the library's own - a copy-in thread and a copy-out thread hand the caller's pageable memory to
+    // hipMemcpyAsync slab by slab (the runtime stages it itself) on two copy streams, overlapped with the kernels and with each other
+    // Measured on MI355X (profiles/r5_host_staging.txt, 1 GiB each way): this form 23.8 ms = 45 GB/s per direction (72 % of the link);
+    // the library's own pinned staging (ADSP_HOST_STAGING=pinned: pageable -> pinned copies by 2 / 4 / 8 host threads per direction,
+    // hipMemcpyAsync from pinned memory) 34.5 / 42.5 / 41.5 ms - the host's memory system, not the link, is what the extra copy costs;
+    // the one-piece form of rounds 1 - 4 (pageable hipMemcpy in, kernel, hipMemcpy out) 38.8 ms.
     const char* mode = getenv("ADSP_HOST_STAGING");
-    const bool direct = mode && strcmp(mode, "direct") == 0;
+    const bool direct = !(mode && strcmp(mode, "pinned") == 0);
     if (hp.slab_bytes < slab_bytes || (!direct && !hp.pin_in[0])) {
         HIP_TRY(hipDeviceSynchronize());
         for (int b = 0; b < 2; ++b) {

@@ -66,6 +66,11 @@
 #define ADSP_MIN_WAVES 1
 #endif
 
+// ADSP_PERSIST: tuning-only (results stay correct): a workgroup of the specialised kernel loops over KernelArgs::blk_iters consecutive blocks
+#ifndef ADSP_PERSIST
+#define ADSP_PERSIST 0
+#endif
+
 namespace adsp {
 
 struct KernelArgs {
@@ -110,6 +115,10 @@ struct KernelArgs {
     unsigned seq_base;             // value of the word when every step before this launch had been published
     unsigned* seq_fail;            // set to 1 by a workgroup that gave up waiting (its block's outputs are then not written)
     unsigned long long seq_timeout;  // in ticks of the constant 100 MHz clock (wall_clock64)
+    int blk_iters;                 // tuning builds with -DADSP_PERSIST=1 only (tools/build_ablations.sh persist): consecutive time blocks ONE workgroup
+                                   // runs through, so that the store drain of block b overlaps the window loads of block b + 1; 1 everywhere else
+    const void* self;              // ... and a copy of these arguments in device memory, which such a workgroup re-reads per block (scalar loads)
+                                   // instead of keeping thirty of them in SGPRs across its loop
 };
 
 // Live sessions (adsp_live_*, round 4): ONE persistent launch consumes ring steps as they are published, for as long as the

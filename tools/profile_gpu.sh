@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # a step is one launch over a resident batch (bench.py): 6 timed launches in batch mode, 768 in stream mode
 case " $* " in *" stream "*) STEPS="--steps 768 --warmup 384";; *) STEPS="--steps 6 --warmup 2";; esac
-BENCH="python $ROOT/bench.py $STEPS --runs 1 --no-parity-check --no-cpu-baseline --no-stream-extra --no-latency --no-graph $*"
+BENCH="python $ROOT/bench.py $STEPS --runs 1 --no-parity-check --no-cpu-baseline --no-stream-extra --no-latency --no-configs --no-graph $*"
 PASSES=${PROF_PASSES:-8}
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $BENCH > $OUT/trace.log 2>&1
 i=0
