@@ -513,6 +513,8 @@ def stream_figures(args, fir, dev, local_rank, world, rank, alg_bytes, channels=
                         "note": "the same single-step launches captured once and replayed as a hipGraph (wall clock over whole replays)"}
     elif getattr(r, "graph_error", None):
         one["graph"] = {"error": r.graph_error}
+    r.graph = None
+    r.eng.close()
     del r
     torch.cuda.empty_cache()
     out = dict(one)
@@ -534,6 +536,7 @@ def stream_figures(args, fir, dev, local_rank, world, rank, alg_bytes, channels=
                        "stream (adsp_ring_acquire_stream + adsp_apply_ring + adsp_ring_join); wall clock, median of 3 (consecutive kernels overlap, so "
                        "there is no per-kernel time: roofline_frac is algorithmic bytes per step over the wall time per step)",
                "one_stream": one}
+        r2.eng.close()
         del r2
         torch.cuda.empty_cache()
     except Exception as exc:
@@ -556,10 +559,19 @@ def stream_figures(args, fir, dev, local_rank, world, rank, alg_bytes, channels=
                                 "note": "adsp_ring_set_pipeline(engine, 3): adsp_ring_acquire_stream + adsp_apply_ring + adsp_ring_join as before, but the steps "
                                         "ride a live session the library runs (one persistent launch, history on chip, 8 bytes of traffic per sample); a step "
                                         "costs the caller one one-lane kernel on its stream; wall clock incl. the final join, median of 3"}
+        # The session must be GONE before anything else is measured: a Runner is kept alive by its own closures until the garbage collector
+        # runs, and an idle session (4098 resident waves polling until their time-out) beside the next figure's session cost that figure 5x
+        # (28 instead of 5.6 us per step, gpurun_out/r5s3).  Winding it down is one call.
+        r3.eng.ring_set_pipeline(1)
+        r3.eng.close()
         del r3
         torch.cuda.empty_cache()
     except Exception as exc:
         out["live_pipeline"] = {"unavailable": f"{type(exc).__name__}: {exc}"[:300]}
+        try:
+            r3.eng.close()
+        except Exception:
+            pass
     return out
 
 
