@@ -140,7 +140,8 @@ using namespace adsp::tables;
 const PlanInfo* find_plan(int M, int FQ, int fmt) {
     int n = 0;
     if (fmt == ADSP_FORMAT_F32) {
-        if (const char* v = getenv("ADSP_PLAN_VARIANT")) {
+        const char* v = getenv("ADSP_PLAN_VARIANT");
+        if (v && *v) {  // (an EMPTY value is "not set": atoi("") would select variant 0 - it did, in two A/B sessions of round 5)
             const PlanInfo* var = adsp::variants_f32(&n);
             const int i = atoi(v);
             if (i >= 0 && i < n && var[i].M == M && var[i].FQ == FQ) return &var[i];

@@ -44,12 +44,15 @@ namespace f64 {
 // workgroups fit a CU - measured on MI355X (profiles/r2_shapes_session4.txt):
 //   M = 8192 : 32 points per thread, 168 VGPRs (3 waves per SIMD), 32 KiB of LDS -> THREE workgroups per CU  (+9 % over two)
 //   M = 16384: 64 points per thread, 4 waves per transform, 64 KiB of LDS        -> TWO workgroups per CU    (+13 % over one)
-// M = 4096 (round 5): 32 points per thread in TWO waves, radices 32 x 8 x 16, in-register pairing, half-buffer exchange (16 KiB), 128 VGPRs
-// without scratch: EIGHT independent transforms per CU.  Rounds 1 - 4 ran this size on the "XL" plan (16 points per thread in four waves,
-// partner bins in lane ^ 32, 32 KiB: four per CU) - chosen in round 1 against a 32-point plan that spilled (190 VGPRs) before the spectrum
-// stage lost its else branches and the exchange its second half.  Measured (profiles/r5_m4096_two_wave_plan.txt, A/B on one box): one launch
-// per chunk 50.6 against 63.0 us of kernel time, the same transforms as a 2N batch 497 000 against 427 000 Msamples/s.  The XL plan stays
-// as tuning variants 26 / 27 (plans_var.hip) and as the plan of live sessions at this size (plans_live.hip).
+// M = 4096 as the 4N transform of N = 2048 batches (round 5): 32 points per thread in TWO waves, radices 32 x 8 x 16, in-register pairing,
+// half-buffer exchange (16 KiB), 128 VGPRs without scratch: EIGHT independent transforms per CU.  Rounds 1 - 4 ran every M = 4096 transform on
+// the "XL" plan (16 points per thread in four waves, partner bins in lane ^ 32, 32 KiB: four per CU) - chosen in round 1 against a 32-point
+// plan that spilled (190 VGPRs) before the spectrum stage lost its else branches and the exchange its second half.  Measured A/B on one box
+// (profiles/r5_m4096_two_wave_plan.txt): N = 2048 batches 543 500 against 500 800 Msamples/s (+8.5 %, 0.549 of the roofline), the EQ at
+// N = 2048 +4 ... 8 %, one launch per chunk with 8192 channels 95.9 against 103.7 us of kernel time, resident launches 48.9 against 52.5 us
+// per step - but one launch per chunk at config 2's own shape (4096 channels: exactly four generations of XL workgroups) 51.5 against 49.4 us,
+// library-pipelined 45.9 either way.  So the F = 2N column (per-chunk launches at N = 4096, the generic kernel's first match) keeps the XL
+// plan and the F = 4N column takes this one; each stays selectable for the other column (variants 22 / 26 / 27, plans_var.hip).
 #ifndef ADSP_PLAN_4096
 #define ADSP_PLAN_4096 Plan<4096, 32, 3, 32, 8, 16, 1, false, true, 4, 3>
 #endif
@@ -78,7 +81,7 @@ namespace f64 {
     make_plan<Plan<1024, 16, 3, 16, 8, 8, 1>, 1, 16, S16, EPI, U4>(),                      \
     make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 8, S16, EPI, U4>(),                     \
     make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 16, S16, EPI, U4>(),                     \
-    make_plan<ADSP_PLAN_4096, 1, 8, S16, EPI, U4>(),                                      \
+    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 8, S16, EPI, U4>(),              \
     make_plan<ADSP_PLAN_4096, 1, 16, S16, EPI, U4>(),                                      \
     make_plan<ADSP_PLAN_8192, 1, 8, S16, EPI, U4>(),                                      \
     make_plan<ADSP_PLAN_8192, 1, 16, S16, EPI, U4>(),                                      \

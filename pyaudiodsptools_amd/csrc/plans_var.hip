@@ -31,12 +31,12 @@ const PlanInfo kVariants[] = {
     make_plan<Plan<512, 16, 3, 16, 4, 8, 1>, 1, 8, false, false>(),                       // 21: one transform per 32-thread workgroup (9.65)
     // round 5: config 2's per-chunk transform (M = 4096) WITHOUT the cross-lane pairing - 32 points per thread in TWO waves, half-buffer
     // exchange (16 KiB), 128 VGPRs: eight independent transforms per CU instead of the XL plan's four
-    make_plan<Plan<4096, 32, 3, 32, 8, 16, 1, false, true, 4>, 1, 8, false, false>(),      // 22: radices 32 x 8 x 16 - since round 5 the DEFAULT plan of this size (plan_table.hpp: ADSP_PLAN_4096)
+    make_plan<Plan<4096, 32, 3, 32, 8, 16, 1, false, true, 4>, 1, 8, false, false>(),      // 22: radices 32 x 8 x 16 (F = 2N column; since round 5 the DEFAULT plan of this size in the F = 4N column, plan_table.hpp: ADSP_PLAN_4096)
     make_plan<Plan<4096, 32, 3, 16, 16, 16, 1, false, true, 4>, 1, 8, false, false>(),     // 23: radices 16 x 16 x 16 (two butterflies per thread and pass)
     make_plan<Plan<4096, 32, 3, 32, 8, 16, 1, false, true, 4>, 2, 8, false, false>(),      // 24: = 22, two transforms per 256-thread workgroup
     make_plan<Plan<4096, 32, 3, 32, 8, 16, 1, false, false, 4>, 1, 8, false, false>(),     // 25: = 22 with the full exchange (32 KiB: four workgroups of two waves per CU)
-    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 8, false, false>(),               // 26: the XL plan, the default for M = 4096 until round 5 (stream: 63.0 against 50.6 us of kernel time per chunk batch)
-    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 16, false, false>(),              // 27: same, F = 4N (N = 2048 batches)
+    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 8, false, false>(),               // 26: the XL plan = the default of the F = 2N column (kept for A/B symmetry)
+    make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 16, false, false>(),              // 27: the XL plan in the F = 4N column, its default until round 5 (N = 2048 batches: 500 800 against 543 500 Msamples/s)
 };
 // also measured and dropped: M = 8192 at four workgroups per CU / 128 VGPRs (spills, = 5), 64 points per thread for M = 8192
 // (-3 % against 5), M = 8192 with radix-16 paired passes (-7 %), one wave per transform with 8 points per thread for M = 512
