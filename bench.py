@@ -288,6 +288,8 @@ class Runner:
         else:
             # whole transform tiles per launch: lcm(chunk, block_outputs) / chunk chunks tile exactly
             tile = int(np.lcm(N, eng.block_outputs) // N)
+            if tile > 128:  # (chunk sizes that share few factors with the kept block, e.g. N = 3000: a whole tile would be a batch of hundreds of chunks)
+                tile = 1
             cps = args.chunks_per_step or 96
             self.cps = cps = -(-cps // tile) * tile
             self.samples_per_step = cps * C * N
