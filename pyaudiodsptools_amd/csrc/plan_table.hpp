@@ -53,6 +53,12 @@ namespace f64 {
 // per step - but one launch per chunk at config 2's own shape (4096 channels: exactly four generations of XL workgroups) 51.5 against 49.4 us,
 // library-pipelined 45.9 either way.  So the F = 2N column (per-chunk launches at N = 4096, the generic kernel's first match) keeps the XL
 // plan and the F = 4N column takes this one; each stays selectable for the other column (variants 22 / 26 / 27, plans_var.hip).
+// ... and the same recipe one more size down for the F = 4N column of M = 2048 (N = 1024 batches): 32 points per thread in ONE wave, radices
+// 32 x 4 x 16, half exchange (8 KiB), 128 VGPRs + 12 B: 550 200 against 515 900 Msamples/s (+6.7 %, 0.556 of the roofline); per chunk at
+// N = 2048 it loses 3 % (49.7 against 47.8 us), so the F = 2N column keeps 16 points per thread in two waves (variants 28 - 30).
+#ifndef ADSP_PLAN_2048_4N
+#define ADSP_PLAN_2048_4N Plan<2048, 32, 3, 32, 4, 16, 1, false, true, 4, 3>
+#endif
 #ifndef ADSP_PLAN_4096
 #define ADSP_PLAN_4096 Plan<4096, 32, 3, 32, 8, 16, 1, false, true, 4, 3>
 #endif
@@ -80,7 +86,7 @@ namespace f64 {
     make_plan<Plan<1024, 16, 3, 16, 8, 8, 1>, 1, 8, S16, EPI, U4>(),                      \
     make_plan<Plan<1024, 16, 3, 16, 8, 8, 1>, 1, 16, S16, EPI, U4>(),                      \
     make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 8, S16, EPI, U4>(),                     \
-    make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 16, S16, EPI, U4>(),                     \
+    make_plan<ADSP_PLAN_2048_4N, 1, 16, S16, EPI, U4>(),                                   \
     make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 8, S16, EPI, U4>(),              \
     make_plan<ADSP_PLAN_4096, 1, 16, S16, EPI, U4>(),                                      \
     make_plan<ADSP_PLAN_8192, 1, 8, S16, EPI, U4>(),                                      \

@@ -37,6 +37,11 @@ const PlanInfo kVariants[] = {
     make_plan<Plan<4096, 32, 3, 32, 8, 16, 1, false, false, 4>, 1, 8, false, false>(),     // 25: = 22 with the full exchange (32 KiB: four workgroups of two waves per CU)
     make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 8, false, false>(),               // 26: the XL plan = the default of the F = 2N column (kept for A/B symmetry)
     make_plan<Plan<4096, 16, 3, 16, 16, 16, 1, true>, 1, 16, false, false>(),              // 27: the XL plan in the F = 4N column, its default until round 5 (N = 2048 batches: 500 800 against 543 500 Msamples/s)
+    // M = 2048 as ONE wave per transform: 32 points per thread, radices 32 x 4 x 16, half exchange (8 KiB), no inter-wave barrier
+    make_plan<Plan<2048, 32, 3, 32, 4, 16, 1, false, true, 4>, 1, 8, false, false>(),      // 28: F = 2N (N = 2048 per chunk)
+    make_plan<Plan<2048, 32, 3, 32, 4, 16, 1, false, true, 4>, 1, 16, false, false>(),     // 29: F = 4N (N = 1024 batches): the DEFAULT of that column since round 5 (plan_table.hpp: ADSP_PLAN_2048_4N)
+    make_plan<Plan<2048, 32, 3, 32, 4, 16, 1, false, true, 4>, 2, 8, false, false>(),      // 30: = 28, two transforms per 128-thread workgroup
+    make_plan<Plan<2048, 16, 3, 16, 16, 8, 1>, 1, 16, false, false>(),                     // 31: the two-wave 16-point plan in the F = 4N column, its default until round 5
 };
 // also measured and dropped: M = 8192 at four workgroups per CU / 128 VGPRs (spills, = 5), 64 points per thread for M = 8192
 // (-3 % against 5), M = 8192 with radix-16 paired passes (-7 %), one wave per transform with 8 points per thread for M = 512

@@ -32,8 +32,9 @@ def test_plans_cover_supported_chunk_sizes():
             assert d["complex_points"] == f // 2
             assert d["threads_per_transform"] * d["points_per_thread"] == f // 2
             full = d["channels_per_workgroup"] * (f // 2) * 8  # one complex64 per point; the large transforms exchange through half a buffer
-            two_wave_4096 = f // 2 == 4096 and f == 4 * n  # round 5: the 4N transform of N = 2048 runs on 32 points per thread in two waves
-            assert d["lds_bytes"] == (full // 2 if f // 2 >= 8192 or two_wave_4096 else full) <= 64 * 1024
+            two_wave_4096 = f // 2 == 4096 and f == 4 * n  # round 5: the 4N transform of N = 2048 runs on 32 points per thread in two waves,
+            one_wave_2048 = f // 2 == 2048 and f == 4 * n  # that of N = 1024 in one: both exchange through half a buffer
+            assert d["lds_bytes"] == (full // 2 if f // 2 >= 8192 or two_wave_4096 or one_wave_2048 else full) <= 64 * 1024
             if f // 2 == 4096:
                 assert (d["points_per_thread"], d["threads_per_transform"]) == ((32, 128) if two_wave_4096 else (16, 256))
             assert (n // 4) % (2 * d["threads_per_transform"]) == 0  # design.py's N/4 granularity is legal
