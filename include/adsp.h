@@ -284,7 +284,7 @@ ADSP_API int adsp_apply_ring(adsp_engine* engine, void* d_out, void* stream);
  * ADSP_ERR_ARG where no session can hold the engine (more channel groups than the GPU keeps resident of that kernel, generic geometry,
  * int16, fused effect): fall back to depth 2.  A session that sees no step for the time-out of adsp_live_configure (default 1 s) ends
  * by itself and the next step starts a fresh one; any call that needs the engine in its ordinary state (adsp_apply_device, the
- * spectrum setters, adsp_reset, a depth change ..) winds the session down first.  The outputs of step k must not be read before a
+ * spectrum setters, adsp_reset, a depth change ..) winds the session down first - after every step submitted so far has been consumed.  The outputs of step k must not be read before a
  * join that follows its adsp_apply_ring. */
 ADSP_API int adsp_ring_set_pipeline(adsp_engine* engine, int depth);
 ADSP_API int adsp_ring_join(adsp_engine* engine, void* stream);

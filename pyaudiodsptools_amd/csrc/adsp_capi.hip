@@ -1708,6 +1708,10 @@ int live_start_impl(adsp_engine* e, void* d_out, int out_slots, unsigned max_ste
         HIP_TRY(hipStreamWaitEvent(stream, e->ev_copy_done, 0));
         e->copy_pending = false;
     }
+    // a stream-ordered filter change (adsp_set_spectrum_async) may still be copying the pair tables on the CALLER's stream: the session
+    // runs on another one and must not start on half-written tables
+    for (int b = 0; b < 2; ++b)
+        if (e->tab_busy[b] && e->ev_tab[b]) HIP_TRY(hipStreamWaitEvent(stream, e->ev_tab[b], 0));
     for (int i = 0; i < 2 * kLiveGpuWords; ++i) L.h_words[i] = 0;
     HIP_TRY(hipMemsetAsync(L.d_words, 0, n_words * sizeof(unsigned), stream));
     adsp::LiveArgs la;
@@ -1995,7 +1999,19 @@ int live_finish(adsp_engine* e, unsigned* steps_consumed, bool idle_timeout_ok) 
 }
 
 // ---- ring steps riding a session (adsp_ring_set_pipeline(engine, 3)) ------------------------------------------------------------
-int live_pipe_release(adsp_engine* e) { return live_finish(e, nullptr, true); }
+// Winding down a session the pipeline owns: every step the caller has submitted is consumed first (their publications sit on the caller's
+// stream and may not have executed yet - stopping at once would drop them), then the session ends.
+int live_pipe_release(adsp_engine* e) {
+    adsp_engine::Live& L = e->live;
+    if (L.published > 0 && host_word_load(L.h_words + kLiveGpuWords + 6) == 0) {  // (still running)
+        const int rc = adsp_live_wait(e, L.published, 20000.0);
+        if (rc) {
+            (void)live_finish(e, nullptr, true);
+            return rc;
+        }
+    }
+    return live_finish(e, nullptr, true);
+}
 
 // can a session run this engine at all?  (the plan exists and every workgroup is resident at once: what adsp_live_start checks)
 int live_pipe_check(adsp_engine* e) {

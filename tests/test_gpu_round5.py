@@ -333,3 +333,75 @@ def test_ring_pipeline_depth_3_is_refused_where_no_session_fits(adsp):
     with pytest.raises(_capi.AdspError):
         eng.ring_set_pipeline(3)
     eng.close()
+
+
+def test_filter_change_in_a_stream_whose_steps_ride_a_session(adsp):
+    """adsp_set_spectrum_async between two ring steps at pipeline depth 3: the session is wound down, the tables are updated on the caller's
+    stream, the next step starts a new session BEHIND that update (the session runs on a stream of its own).  A streaming FIR's output
+    depends on the input history only, so the steps after the change equal the new filter applied to the whole stream."""
+    import ctypes
+    import torch
+    from pyaudiodsptools_amd import FirEngine, FirStream, design
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    n, channels, steps, cut = 512, 300, 24, 11
+    fir_a = FirStream(design.lowcut_kernel(300, 44100, n), n)
+    fir_b = FirStream(design.highcut_kernel(3000, 44100, n), n)
+    x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=torch.Generator(device="cuda").manual_seed(77))
+    ta, tb = _exact(adsp, fir_a, x), _exact(adsp, fir_b, x)
+    eng = FirEngine(fir_a, channels=channels, ring_slots=8, optimize_for="stream")
+    assert eng.ring_set_pipeline("auto") == 3
+    y = torch.zeros_like(x)
+    user = torch.cuda.Stream()
+    sp = user.cuda_stream
+    for k in range(steps):
+        if k == cut:  # (no join before it: winding the session down consumes every submitted step first)
+            eng.set_fir(fir_b, stream=sp, live=True)
+        slot = eng.ring_acquire(sp)
+        assert hip.hipMemcpyAsync(slot, x[k].data_ptr(), channels * n * 4, 3, sp) == 0
+        eng.apply_ring(y[k], sp)
+    eng.ring_join(sp)
+    user.synchronize()
+    scale = float(max(ta.abs().max(), tb.abs().max()))
+    assert float((y[:cut] - ta[:cut]).abs().max()) <= 1e-5 * scale and float((y[cut:] - tb[cut:]).abs().max()) <= 1e-5 * scale
+    eng.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_upols_engine_randomised_shapes(adsp, seed):
+    """Seeded random long-kernel streams (chunk sizes that are multiples of 4, kernels of 1.1 - 3 chunks, any delay, 1 - 40 channels, calls
+    of 1 - 3 chunks with sub-call splitting, float32 / int16): every sample against the float64 direct sum on the GPU."""
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(2500, 10000)) * 4
+    taps_len = int(rng.integers(max(33000, int(1.1 * n)), 3 * n))
+    latency = int(rng.integers(1, 4))
+    lookahead = int(rng.integers(0, max(1, latency * n - 8192 - 4)))   # delay = latency * n - lookahead >= a block
+    channels = int(rng.integers(1, 41))
+    calls = [int(c) for c in rng.integers(1, 4, size=int(rng.integers(2, 5)))]
+    fmt = "s16" if seed % 4 == 3 else "f32"
+    taps = rng.standard_normal(taps_len) * np.hanning(taps_len) / np.sqrt(taps_len) * 2.0
+    fir = adsp.FirStream(taps, n, latency_chunks=latency, lookahead=lookahead)
+    eng = adsp.UpolsFirEngine(fir, channels=channels, sample_format=fmt, max_steps=int(rng.integers(1, 3)))
+    steps = sum(calls)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    if fmt == "s16":
+        x = torch.randint(-9000, 9000, (steps, channels, n), device="cuda", dtype=torch.int16, generator=g)
+    else:
+        x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=g)
+    y = torch.empty_like(x)
+    s = torch.cuda.current_stream().cuda_stream
+    pos = 0
+    for k in calls:
+        eng.apply_device(x[pos:pos + k], y[pos:pos + k], k, s)
+        pos += k
+    torch.cuda.synchronize()
+    t = _exact(adsp, fir, x, fmt)
+    what = f"seed {seed}: N={n} taps={taps_len} latency={latency} lookahead={lookahead} C={channels} calls={calls} {fmt}"
+    if fmt == "s16":
+        diff = (y.int() - t.int()).abs()
+        assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) <= 0.01, what
+    else:
+        scale = float(t.abs().max())
+        assert scale > 0.05 and float((y - t).abs().max()) <= 1e-5 * scale, what
+    eng.close()
