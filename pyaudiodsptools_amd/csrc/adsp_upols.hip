@@ -40,6 +40,14 @@
 
 using adsp::fail;
 
+// tuning (tools/sessions/r5_session12.sh): stages of the multiply kernel requested ahead, and its workgroups per CU
+#ifndef ADSP_UPOLS_AHEAD
+#define ADSP_UPOLS_AHEAD 4
+#endif
+#ifndef ADSP_UPOLS_MAC_WAVES
+#define ADSP_UPOLS_MAC_WAVES 2
+#endif
+
 namespace adsp {
 
 struct UpolsArgs {
@@ -50,7 +58,7 @@ struct UpolsArgs {
     const float4* tw;    // pass twiddles of the plan
     const float4* pair;  // [P] pair tables (complex form), pair_stride float4 each
     const float2* pair0; // [P] tables of thread 0's self-paired butterflies, pair0_stride float2 each
-    float2* zline;       // [C][R][PTS][T] float2: the delay line of forward-transformed blocks
+    float2* zline;       // [C][R][PTS/2][T] float4: the delay line of forward-transformed blocks (two registers per unit: upols_forward_kernel)
     int ring_pos, ring_slots, C, N, nh, n_steps;
     float inv_n;
     int P;               // partitions
@@ -155,14 +163,21 @@ __global__ __launch_bounds__(PL::T, 3) void upols_forward_kernel(const UpolsArgs
 
     int slot = a.slot_first + blk;
     slot -= slot >= a.R ? a.R : 0;
-    float2* z = a.zline + (static_cast<size_t>(c) * a.R + slot) * (static_cast<size_t>(P) * T) + tid;
+    // the delay line holds a block as the multiply kernel reads it: 16 bytes per lane and load - unit 2h = the registers (NB 2h, NB (2h+1))
+    // of the paired butterflies' first sides, unit 2h+1 = their partners (NB (R-1-2h) + 1, NB (R-2-2h) + 1); read back by the next launch (L2)
+    constexpr int RR = PL::RL, NB = PL::NBL;
+    float4* z = reinterpret_cast<float4*>(a.zline) + (static_cast<size_t>(c) * a.R + slot) * (static_cast<size_t>(P / 2) * T) + tid;
 #pragma unroll
-    for (int m = 0; m < P; ++m) z[static_cast<size_t>(m) * T] = make_float2(xr[m], xi[m]);  // read back by the next launch (L2)
+    for (int h = 0; h < RR / 2; ++h) {
+        const int a0 = NB * (2 * h), a1 = NB * (2 * h + 1), b0 = NB * (RR - 1 - 2 * h) + 1, b1 = NB * (RR - 2 - 2 * h) + 1;
+        z[static_cast<size_t>(2 * h) * T] = make_float4(xr[a0], xi[a0], xr[a1], xi[a1]);
+        z[static_cast<size_t>(2 * h + 1) * T] = make_float4(xr[b0], xi[b0], xr[b1], xi[b1]);
+    }
 }
 
 // ---- launch 2: sum over partitions of pair_op_p(Z_{b-p}) -> inverse passes -> kept half ----------------------------------
 template <class PL, bool S16>
-__global__ __launch_bounds__(PL::T, 3) void upols_mac_kernel(const UpolsArgs a) {
+__global__ __launch_bounds__(PL::T, ADSP_UPOLS_MAC_WAVES) void upols_mac_kernel(const UpolsArgs a) {
     constexpr int P = PL::P, T = PL::T, R = PL::RL, NB = PL::NBL;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     real2* lds = reinterpret_cast<real2*>(smem_raw);
@@ -173,59 +188,118 @@ __global__ __launch_bounds__(PL::T, 3) void upols_mac_kernel(const UpolsArgs a) 
     real ar[P], ai[P];
 #pragma unroll
     for (int m = 0; m < P; ++m) ar[m] = ai[m] = 0.f;
-    const float2* zc = a.zline + static_cast<size_t>(c) * a.R * (static_cast<size_t>(P) * T) + tid;
-    for (int p = 0; p < a.P; ++p) {
+    constexpr size_t kSlot = static_cast<size_t>(P) * T;
+    const float2* zc = a.zline + static_cast<size_t>(c) * a.R * kSlot;
+    auto block_of = [&](int p) {
         int slot = a.slot_first + blk - p;
         slot += slot < 0 ? a.R : 0;
         slot -= slot >= a.R ? a.R : 0;
-        const float2* z = zc + static_cast<size_t>(slot) * (static_cast<size_t>(P) * T);
-        const float4* tab = a.pair + static_cast<size_t>(p) * a.pair_stride;
-        const float2* tab0 = a.pair0 + static_cast<size_t>(p) * a.pair0_stride;
-        auto accumulate = [&](int ia, int ib, const float2 c1, const float2 c2, const float2 c4) {
-            const float2 va = z[static_cast<size_t>(ia) * T];
-            float zar = va.x, zai = va.y, zbr, zbi;
-            if (ia == ib) {  // a bin that pairs with itself (k = 0 and k = M/2 of thread 0)
-                zbr = zar;
-                zbi = zai;
-            } else {
-                const float2 vb = z[static_cast<size_t>(ib) * T];
-                zbr = vb.x;
-                zbi = vb.y;
-            }
-            pair_op(zar, zai, zbr, zbi, c1, c2, c4);
-            ar[ia] += zar;
-            ai[ia] += zai;
-            if (ia != ib) {
-                ar[ib] += zbr;
-                ai[ib] += zbi;
+        return zc + static_cast<size_t>(slot) * kSlot;
+    };
+
+    // Thread 0's self-paired butterflies j = 0 (registers NB r) and j = M/R/2 (NB r + 1): 17 pairs, entries as in spectrum_stage.
+    // Lane e of the first wave takes pair e through all partitions; the sums wait for thread 0 in the (still idle) exchange buffer.
+    // First, while the accumulators are not live yet.
+    constexpr int kSelf = 2 + (R / 2 - 1) + R / 2;
+    if (tid < kSelf) {
+        int ia, ib;
+        if (tid == 0) ia = ib = 0;
+        else if (tid == 1) ia = ib = NB * (R / 2);
+        else if (tid < 2 + (R / 2 - 1)) ia = NB * (tid - 1), ib = NB * (R - (tid - 1));
+        else ia = NB * (tid - (2 + R / 2 - 1)) + 1, ib = NB * (R - 1 - (tid - (2 + R / 2 - 1))) + 1;
+        auto where = [&](int m) {  // register m of thread 0 in a block of the delay line (float2 units): see upols_forward_kernel
+            const bool partner = m & 1;
+            const int q = partner ? R - 1 - m / NB : m / NB;
+            return ((q & ~1) + (partner ? 1 : 0)) * T * 2 + (q & 1);
+        };
+        float sar = 0.f, sai = 0.f, sbr = 0.f, sbi = 0.f;
+#pragma unroll 4
+        for (int p = 0; p < a.P; ++p) {
+            const float2* z = block_of(p);
+            const float2* tab0 = a.pair0 + static_cast<size_t>(p) * a.pair0_stride + tid * 3;
+            const float2 va = z[where(ia)], vb = z[where(ib)];  // (ia == ib: the bin pairs with itself)
+            float zar = va.x, zai = va.y, zbr = vb.x, zbi = vb.y;
+            pair_op(zar, zai, zbr, zbi, tab0[0], tab0[1], tab0[2]);
+            sar += zar;
+            sai += zai;
+            sbr += zbr;
+            sbi += zbi;
+        }
+        lds[ib] = make_float2(sbr, sbi);
+        lds[ia] = make_float2(sar, sai);  // (second: a self-paired bin keeps its first output)
+    }
+
+    // Every lane runs the regular pairing (register NB r of butterfly tid with register NB (R-1-r) + 1 of its mirror) as one
+    // stream of stages - a stage is two pairs: three float4 of table, four float2 of spectrum - with kAhead stages requested
+    // ahead of the one being multiplied, across partition boundaries.  Lane 0's butterflies pair with THEMSELVES: what it
+    // accumulates here is replaced by the sums above.
+    struct Stage {
+        float4 f0, f1, f2;
+        float4 za, zb;  // (register NB 2h, register NB (2h+1)) and their partners: the delay line's units 2h, 2h+1
+    };
+    constexpr int kStages = R / 2, kAhead = ADSP_UPOLS_AHEAD;
+    static_assert(kStages % kAhead == 0, "the stage ring is indexed at compile time");
+    Stage st[kAhead];
+    // buffer loads of 16 bytes per lane (the vector-memory path takes ~7 ns per wave instruction whatever its width: micro/tcp_rate.hip):
+    // one lane offset, everything else is a scalar offset - 40 global addresses per partition would otherwise be kept in registers
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    auto as_f4 = [](v4u u) { return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)); };
+    const int lane16 = tid * 16;
+    auto request = [&](Stage& s, const float2* z, const float4* tab, int h) {
+        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(tab), 0, kStages * 3 * T * 16, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(z), 0, static_cast<int>(kSlot) * 8, 0x00020000);
+        s.f0 = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rt, lane16, (h * 3 + 0) * T * 16, 0));
+        s.f1 = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rt, lane16, (h * 3 + 1) * T * 16, 0));
+        s.f2 = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rt, lane16, (h * 3 + 2) * T * 16, 0));
+        s.za = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rz, lane16, (2 * h) * T * 16, 0));
+        s.zb = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rz, lane16, (2 * h + 1) * T * 16, 0));
+    };
+    auto multiply = [&](const Stage& s, int h) {
+        const int r0 = 2 * h, r1 = 2 * h + 1;
+        float zar = s.za.x, zai = s.za.y, zbr = s.zb.x, zbi = s.zb.y;
+        pair_op(zar, zai, zbr, zbi, make_float2(s.f0.x, s.f0.y), make_float2(s.f0.z, s.f0.w), make_float2(s.f1.x, s.f1.y));
+        ar[NB * r0] += zar;
+        ai[NB * r0] += zai;
+        ar[NB * (R - 1 - r0) + 1] += zbr;
+        ai[NB * (R - 1 - r0) + 1] += zbi;
+        zar = s.za.z, zai = s.za.w, zbr = s.zb.z, zbi = s.zb.w;
+        pair_op(zar, zai, zbr, zbi, make_float2(s.f1.z, s.f1.w), make_float2(s.f2.x, s.f2.y), make_float2(s.f2.z, s.f2.w));
+        ar[NB * r1] += zar;
+        ai[NB * r1] += zai;
+        ar[NB * (R - 1 - r1) + 1] += zbr;
+        ai[NB * (R - 1 - r1) + 1] += zbi;
+    };
+    {
+        const float2* z = block_of(0);
+        const float4* tab = a.pair;
+#pragma unroll
+        for (int h = 0; h < kAhead; ++h) request(st[h], z, tab, h);
+        auto partition = [&](auto more, const float2* zn, const float4* tabn) {  // straight-line code: no branch inside a partition
+#pragma unroll
+            for (int h = 0; h < kStages; ++h) {
+                multiply(st[h % kAhead], h);
+                if (h + kAhead < kStages) request(st[h % kAhead], z, tab, h + kAhead);
+                else if constexpr (decltype(more)::value) request(st[h % kAhead], zn, tabn, h + kAhead - kStages);
+                __builtin_amdgcn_sched_barrier(0);  // keep the requests where they are: kAhead stages of registers, not a partition's
             }
         };
-        // two sequential ifs, not if / else (register liveness over the linearised control flow: fftconv_core.inc, spectrum_stage)
-        if (tid != 0) {
-#pragma unroll
-            for (int h = 0; h < R / 2; ++h) {
-                const float4 f0 = tab[(h * 3 + 0) * T + tid];
-                const float4 f1 = tab[(h * 3 + 1) * T + tid];
-                const float4 f2 = tab[(h * 3 + 2) * T + tid];
-                const int r0 = 2 * h, r1 = 2 * h + 1;
-                accumulate(NB * r0, NB * (R - 1 - r0) + 1, make_float2(f0.x, f0.y), make_float2(f0.z, f0.w), make_float2(f1.x, f1.y));
-                accumulate(NB * r1, NB * (R - 1 - r1) + 1, make_float2(f1.z, f1.w), make_float2(f2.x, f2.y), make_float2(f2.z, f2.w));
-            }
+        for (int p = 1; p < a.P; ++p) {
+            const float2* zn = block_of(p);
+            const float4* tabn = tab + a.pair_stride;
+            partition(std::true_type{}, zn, tabn);
+            z = zn;
+            tab = tabn;
         }
-        if (tid == 0) {
-            // thread 0: the self-paired butterflies j = 0 (registers NB r) and j = M/R/2 (NB r + 1); entries as in spectrum_stage
-            accumulate(0, 0, tab0[0], tab0[1], tab0[2]);
-            accumulate(NB * (R / 2), NB * (R / 2), tab0[3], tab0[4], tab0[5]);
+        partition(std::false_type{}, z, tab);
+    }
+
+    __syncthreads();
+    if (tid == 0) {
 #pragma unroll
-            for (int r = 1; r < R / 2; ++r) {
-                const int e = 2 + (r - 1);
-                accumulate(NB * r, NB * (R - r), tab0[e * 3], tab0[e * 3 + 1], tab0[e * 3 + 2]);
-            }
-#pragma unroll
-            for (int r = 0; r < R / 2; ++r) {
-                const int e = 2 + (R / 2 - 1) + r;
-                accumulate(NB * r + 1, NB * (R - 1 - r) + 1, tab0[e * 3], tab0[e * 3 + 1], tab0[e * 3 + 2]);
-            }
+        for (int m = 0; m < P; ++m) {
+            const real2 v = lds[m];
+            ar[m] = v.x;
+            ai[m] = v.y;
         }
     }
     int ja, jb;
