@@ -41,7 +41,7 @@ extern "C" {
 #define ADSP_API
 #endif
 
-#define ADSP_ABI_VERSION 9
+#define ADSP_ABI_VERSION 10
 #define ADSP_MAX_HISTORY 8
 
 typedef enum adsp_status {
@@ -506,7 +506,8 @@ ADSP_API int adsp_exact_apply_host(adsp_exact* fir, const void* in, void* out, i
 /* ---------------------------------------------------------------------------------------------------------------
  * Uniformly partitioned engines (round 5): streaming FIRs LONGER than one transform - the reference's own GPU example runs
  * chunk_size 88200 (Example4.py:5, ModuleTestsGPU.py:35: CreateLowCutFilter -> 44 099 taps, CreateEQ3BandFFT -> 88 197).
- *     out[tau] = y[tau - delay],   y = taps (*) s   (zero history),   taps cut into P partitions of B = adsp_upols_block_size() taps
+ *     out[tau] = y[tau - delay],   y = taps (*) s   (zero history),   taps cut into P partitions of B taps, B one of
+ *     adsp_upols_block_sizes() (8192, 16384: per output sample the second launch reads P x 20 bytes - the largest B <= delay is the fastest)
  * Every input block of B samples is transformed ONCE (2B-point real FFT), its spectrum kept in a frequency-domain delay line in HBM;
  * an output block is ONE inverse transform of sum_p X_{b-p} H_p.  Two launches per call (forward transforms; multiply-accumulate +
  * inverse + store), each over every (channel, block) at once - instead of one full engine pass per kernel slice.
@@ -524,13 +525,14 @@ typedef struct adsp_upols_config {
     int device_id;
     int chunk_size;
     int n_channels;
-    int block_size;     /* must equal adsp_upols_block_size() */
+    int block_size;     /* one of adsp_upols_block_sizes() */
     int n_partitions;
     int delay;
     int sample_format;  /* ADSP_FORMAT_F32 or ADSP_FORMAT_S16 */
     int max_steps;
 } adsp_upols_config;
-ADSP_API int adsp_upols_block_size(void);
+ADSP_API int adsp_upols_block_size(void);                       /* the smallest block size of this build */
+ADSP_API int adsp_upols_block_sizes(int* sizes, int capacity);  /* ascending; returns how many there are (also with sizes == NULL) */
 ADSP_API int adsp_upols_create(const adsp_upols_config* cfg, const float* spectra, adsp_upols** out);
 ADSP_API void adsp_upols_destroy(adsp_upols* fir);
 ADSP_API int adsp_upols_reset(adsp_upols* fir); /* history and delay line back to zeros */

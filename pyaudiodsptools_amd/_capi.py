@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADSP_LIB") or os.path.join(_HERE, "libadsp.so")  # ADSP_LIB: tuning builds only
 
-ADSP_ABI_VERSION = 9
+ADSP_ABI_VERSION = 10
 ADSP_MAX_HISTORY = 8
 ADSP_RCCL_UNIQUE_ID_BYTES = 128
 ADSP_FORMAT_F32, ADSP_FORMAT_S16, ADSP_FORMAT_S16_F64 = 0, 1, 2
@@ -110,6 +110,7 @@ SIGNATURES = {
     "adsp_exact_apply_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "adsp_exact_apply_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "adsp_upols_block_size": (ctypes.c_int, []),
+    "adsp_upols_block_sizes": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "adsp_upols_create": (ctypes.c_int, [ctypes.POINTER(AdspUpolsConfig), ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
     "adsp_upols_destroy": (None, [ctypes.c_void_p]),
     "adsp_upols_reset": (ctypes.c_int, [ctypes.c_void_p]),

@@ -97,7 +97,7 @@ __device__ __forceinline__ bool upols_block(const UpolsArgs& a, int& c, int& blk
 
 // ---- launch 1: window -> forward passes -> delay line ----------------------------------------------------------------
 template <class PL, bool S16>
-__global__ __launch_bounds__(PL::T, 3) void upols_forward_kernel(const UpolsArgs a) {
+__global__ __launch_bounds__(PL::T, PL::P > 32 ? 2 : 3) void upols_forward_kernel(const UpolsArgs a) {
     constexpr int P = PL::P, T = PL::T;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     real2* lds = reinterpret_cast<real2*>(smem_raw);
@@ -360,18 +360,41 @@ __global__ __launch_bounds__(PL::T, ADSP_UPOLS_MAC_WAVES) void upols_mac_kernel(
 namespace {
 using namespace adsp;
 using namespace adsp::tables;
-using UPL = ADSP_PLAN_8192;  // B = 8192: 32 points per thread, 256 threads, half-buffer exchanges (32 KiB of LDS)
-constexpr int kB = UPL::M;
+// The block sizes of this build: B = 8192 on the 32-points-per-thread plan (32 KiB of LDS, three / two workgroups per CU) and
+// B = 16384 on the 64-points-per-thread plan (64 KiB, two workgroups per CU).  Per output sample the multiply launch reads
+// n_partitions x 20 bytes, and n_partitions = ceil(taps / B): the larger block halves what bounds the engine, for ~8 % more transform work.
+struct UpolsPlan {
+    int block, threads, lds_bytes;
+    PlanInfo shape;
+    const void* fwd[2];  // [sample format: f32, s16]
+    const void* mac[2];
+};
 
-constexpr PlanInfo upols_plan_shape() {
-    return PlanInfo{UPL::M, 8, UPL::P, UPL::T, 1, UPL::NP, UPL::XL ? 1 : 0, {UPL::fwd(0), UPL::fwd(1), UPL::fwd(2), UPL::fwd(3)},
-                    UPL::tw_total, UPL::LDS_ELEMS * (int)sizeof(float2), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+template <class PL>
+UpolsPlan upols_plan() {
+    UpolsPlan p;
+    p.block = PL::M;
+    p.threads = PL::T;
+    p.lds_bytes = PL::LDS_ELEMS * (int)sizeof(float2);
+    p.shape = PlanInfo{PL::M, 8, PL::P, PL::T, 1, PL::NP, PL::XL ? 1 : 0, {PL::fwd(0), PL::fwd(1), PL::fwd(2), PL::fwd(3)},
+                       PL::tw_total, PL::LDS_ELEMS * (int)sizeof(float2), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    p.fwd[0] = reinterpret_cast<const void*>(&upols_forward_kernel<PL, false>);
+    p.fwd[1] = reinterpret_cast<const void*>(&upols_forward_kernel<PL, true>);
+    p.mac[0] = reinterpret_cast<const void*>(&upols_mac_kernel<PL, false>);
+    p.mac[1] = reinterpret_cast<const void*>(&upols_mac_kernel<PL, true>);
+    return p;
 }
-constexpr int kLds = UPL::LDS_ELEMS * (int)sizeof(float2);
+
+const UpolsPlan* upols_plans(int* count) {
+    static const UpolsPlan plans[] = {upols_plan<ADSP_PLAN_8192>(), upols_plan<ADSP_PLAN_16384>()};
+    if (count) *count = (int)(sizeof plans / sizeof plans[0]);
+    return plans;
+}
 }  // namespace
 
 struct adsp_upols {
     adsp_upols_config cfg;
+    const UpolsPlan* plan;
     int nh, ring_slots, ring_pos, R;
     long long steps_done;  // chunks consumed so far: the call's first new sample has absolute index steps_done * N
     long long fwd_done;    // every block <= this one has been transformed (-1 at stream start: blocks before it are all zeros)
@@ -389,7 +412,7 @@ struct adsp_upols {
     size_t stage_bytes;
     size_t ssize() const { return cfg.sample_format == ADSP_FORMAT_F32 ? sizeof(float) : sizeof(short); }
     size_t plane_bytes() const { return (size_t)cfg.n_channels * cfg.chunk_size * ssize(); }
-    size_t zline_bytes() const { return (size_t)cfg.n_channels * R * kB * sizeof(float2); }
+    size_t zline_bytes() const { return (size_t)cfg.n_channels * R * plan->block * sizeof(float2); }
 };
 
 namespace {
@@ -398,7 +421,11 @@ long long floor_div(long long a, long long b) { return a >= 0 ? a / b : -((-a + 
 int upols_launch_pair(adsp_upols* u, const void* d_in, void* d_out, int n, hipStream_t stream) {
     const adsp_upols_config& c = u->cfg;
     const long long N = c.chunk_size, t_call = u->steps_done * N, t_end = t_call + (long long)n * N;
+    const UpolsPlan& pl = *u->plan;
+    const long long kB = pl.block;
+    void* kargs[] = {nullptr};
     UpolsArgs a;
+    kargs[0] = &a;
     memset(&a, 0, sizeof a);
     a.ring = u->ring;
     a.in = d_in;
@@ -436,9 +463,7 @@ int upols_launch_pair(adsp_upols* u, const void* d_in, void* d_out, int n, hipSt
         if ((long long)a.rel_first + (long long)u->nh * N < 0) return fail(ADSP_ERR_STATE, "internal: block %lld starts before the input history", b0);
         const long long grid = groups * a.nblk;
         if (grid > 0x7fffffffLL) return fail(ADSP_ERR_ARG, "launch too large (%lld workgroups)", grid);
-        if (s16) hipLaunchKernelGGL((upols_forward_kernel<UPL, true>), dim3((unsigned)grid), dim3(UPL::T), kLds, stream, a);
-        else hipLaunchKernelGGL((upols_forward_kernel<UPL, false>), dim3((unsigned)grid), dim3(UPL::T), kLds, stream, a);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipLaunchKernel(pl.fwd[s16 ? 1 : 0], dim3((unsigned)grid), dim3(pl.threads), kargs, pl.lds_bytes, stream));
         u->fwd_done = b_fwd_hi;
     }
     // 2. multiply-accumulate + inverse: the blocks of y that meet this call's outputs, y index tau - delay for tau in [t_call, t_end)
@@ -450,9 +475,7 @@ int upols_launch_pair(adsp_upols* u, const void* d_in, void* d_out, int n, hipSt
     a.rel_first = (int)(b_lo * kB + c.delay - t_call);  // output time of the block's first kept sample (circular index B)
     const long long grid = groups * a.nblk;
     if (grid > 0x7fffffffLL) return fail(ADSP_ERR_ARG, "launch too large (%lld workgroups)", grid);
-    if (s16) hipLaunchKernelGGL((upols_mac_kernel<UPL, true>), dim3((unsigned)grid), dim3(UPL::T), kLds, stream, a);
-    else hipLaunchKernelGGL((upols_mac_kernel<UPL, false>), dim3((unsigned)grid), dim3(UPL::T), kLds, stream, a);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipLaunchKernel(pl.mac[s16 ? 1 : 0], dim3((unsigned)grid), dim3(pl.threads), kargs, pl.lds_bytes, stream));
     // 3. the ring keeps the last nh chunks (read by the next call's forward launch): stream-ordered copies behind the kernels
     const size_t plane = u->plane_bytes();
     const int cnt = n < u->nh ? n : u->nh;
@@ -468,12 +491,25 @@ int upols_launch_pair(adsp_upols* u, const void* d_in, void* d_out, int n, hipSt
 
 extern "C" {
 
-int adsp_upols_block_size(void) { return kB; }
+int adsp_upols_block_size(void) { return upols_plans(nullptr)[0].block; }
+
+int adsp_upols_block_sizes(int* sizes, int capacity) {
+    int n = 0;
+    const UpolsPlan* plans = upols_plans(&n);
+    for (int i = 0; i < n && sizes && i < capacity; ++i) sizes[i] = plans[i].block;
+    return n;
+}
 
 int adsp_upols_create(const adsp_upols_config* cfg, const float* spectra, adsp_upols** out) {
     if (!cfg || !spectra || !out) return fail(ADSP_ERR_ARG, "NULL argument");
     *out = nullptr;
-    if (cfg->block_size != kB) return fail(ADSP_ERR_ARG, "block_size %d: this build partitions into blocks of %d samples (adsp_upols_block_size)", cfg->block_size, kB);
+    int n_plans = 0;
+    const UpolsPlan* plans = upols_plans(&n_plans);
+    const UpolsPlan* plan = nullptr;
+    for (int i = 0; i < n_plans; ++i)
+        if (plans[i].block == cfg->block_size) plan = &plans[i];
+    if (!plan) return fail(ADSP_ERR_ARG, "block_size %d: this build partitions into blocks of %d or %d samples (adsp_upols_block_sizes)", cfg->block_size, plans[0].block, plans[n_plans - 1].block);
+    const int kB = plan->block;
     if (cfg->chunk_size < 16 || cfg->chunk_size % 4) return fail(ADSP_ERR_ARG, "chunk_size %d: partitioned engines need a multiple of 4, >= 16", cfg->chunk_size);
     if (cfg->n_channels <= 0) return fail(ADSP_ERR_ARG, "n_channels must be positive");
     if (cfg->n_partitions < 1 || cfg->n_partitions > 4096) return fail(ADSP_ERR_ARG, "n_partitions %d out of range 1..4096", cfg->n_partitions);
@@ -493,6 +529,7 @@ int adsp_upols_create(const adsp_upols_config* cfg, const float* spectra, adsp_u
     adsp_upols* u = new adsp_upols();
     memset(static_cast<void*>(u), 0, sizeof *u);
     u->cfg = *cfg;
+    u->plan = plan;
     const int N = cfg->chunk_size;
     u->nh = (2 * kB + N - 1) / N;  // the oldest window a call opens starts less than two blocks before the call's first sample
     u->ring_slots = u->nh + 1;
@@ -507,9 +544,8 @@ int adsp_upols_create(const adsp_upols_config* cfg, const float* spectra, adsp_u
     };
     hipError_t err;
     if ((err = hipSetDevice(cfg->device_id)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(err)));
-    for (const void* fn : {reinterpret_cast<const void*>(&upols_forward_kernel<UPL, false>), reinterpret_cast<const void*>(&upols_forward_kernel<UPL, true>),
-                           reinterpret_cast<const void*>(&upols_mac_kernel<UPL, false>), reinterpret_cast<const void*>(&upols_mac_kernel<UPL, true>)})
-        if ((err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLds)) != hipSuccess)
+    for (const void* fn : {plan->fwd[0], plan->fwd[1], plan->mac[0], plan->mac[1]})
+        if ((err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, plan->lds_bytes)) != hipSuccess)
             return bail(fail(ADSP_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(err)));
     const size_t ring_bytes = (size_t)u->ring_slots * u->plane_bytes();
     if ((err = hipMalloc(&u->ring, ring_bytes)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc ring (%zu bytes): %s", ring_bytes, hipGetErrorString(err)));
@@ -521,7 +557,7 @@ int adsp_upols_create(const adsp_upols_config* cfg, const float* spectra, adsp_u
                          (int)(kB * sizeof(float2)), hipGetErrorString(err)));
     if ((err = hipMemset(u->zline, 0, u->zline_bytes())) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMemset: %s", hipGetErrorString(err)));
     // tables: the plan's twiddles, and per partition the pair tables of its spectrum - built exactly like an engine's
-    const PlanInfo pl = upols_plan_shape();
+    const PlanInfo pl = plan->shape;
     std::vector<float4> tw;
     build_twiddles<float>(pl, tw);
     if ((int)tw.size() != pl.tw_total) return bail(fail(ADSP_ERR_STATE, "internal: twiddle count %zu != %d", tw.size(), pl.tw_total));

@@ -281,6 +281,19 @@ class UniformPartition:
     spectra: np.ndarray  # float32 [n_partitions, block + 1, 2]: rfft of each piece zero-padded to 2 * block
 
 
+def choose_uniform_block(fir: "FirStream", channels: int, sizes=(8192, 16384)) -> int:
+    """Block size of a uniformly partitioned engine: of the sizes the stream's delay allows (partition_uniform: delay >= block), the
+    largest one once a call has enough blocks to fill the chip several times over - the multiply launch reads taps / B x 20 bytes per
+    output sample - and the smallest one below that, where more and shorter workgroups win (measured, profiles/r5_upols_block_16384.txt:
+    1024 channels x 88200: -3 % / -10 % with 16384; 64 channels: +16 % / +11 %)."""
+    delay = int(fir.delay) - int(fir.delay) % 4
+    valid = sorted(b for b in sizes if b <= delay)
+    if not valid:
+        return min(sizes)  # (partition_uniform raises for it)
+    big = valid[-1]
+    return big if int(channels) * int(fir.chunk_size) >= 2048 * big else valid[0]
+
+
 def partition_uniform(fir: FirStream, block: int, gain: float = 1.0) -> UniformPartition:
     """Cut `fir` into partitions of `block` taps.  The stream delay fir.delay (= latency_chunks * N - lookahead) is rounded DOWN to a
     multiple of 4 samples - the kernels move four samples per access - by delaying the kernel by the remainder instead (0..3 leading

@@ -9,7 +9,8 @@ import ctypes
 import numpy as np
 
 from . import _capi
-from .design import PCM16_GAIN, FirStream, engine_spectrum, fits_one_transform, overlap_save_geometry, partition, partition_uniform
+from .design import (PCM16_GAIN, FirStream, choose_uniform_block, engine_spectrum, fits_one_transform, overlap_save_geometry, partition,
+                     partition_uniform)
 
 _FORMATS = {"f32": (_capi.ADSP_FORMAT_F32, np.float32), "s16": (_capi.ADSP_FORMAT_S16, np.int16),
             "s16_f64": (_capi.ADSP_FORMAT_S16_F64, np.int16)}  # int16 samples, float64 arithmetic (the exact-FFT engines)
@@ -468,12 +469,19 @@ class PartitionedFirEngine:
 
 class UpolsFirEngine:
     """A FIR longer than one transform as ONE uniformly partitioned engine (adsp_upols_*, csrc/adsp_upols.hip): every input block of
-    B = 8192 samples is transformed once, its spectrum kept in a frequency-domain delay line in HBM, and an output block is one
+    B samples (`block`: 8192 or 16384, default design.choose_uniform_block: the larger one where the delay allows it and a call has
+    blocks enough to fill the chip several times) is transformed once, its spectrum kept in a frequency-domain delay line in HBM, and an output block is one
     inverse transform of sum_p X_{b-p} H_p - two launches per call instead of PartitionedFirEngine's full engine pass per kernel
     slice.  float32 or int16 batches, a stateless effect fused on the output registers.  The reference shape: Example4.py:5 /
     ModuleTestsGPU.py:35 (chunk 88200: 44 099 / 88 197 taps)."""
 
-    def __init__(self, fir: FirStream, channels=1, device=0, sample_format="f32", max_steps=1, optimize_for="stream"):
+    @staticmethod
+    def block_sizes():
+        lib = _capi.load()
+        sizes = (ctypes.c_int * 8)()
+        return [int(v) for v in sizes[:lib.adsp_upols_block_sizes(sizes, 8)]]
+
+    def __init__(self, fir: FirStream, channels=1, device=0, sample_format="f32", max_steps=1, optimize_for="stream", block=None):
         self._lib = _capi.load()
         self._h = ctypes.c_void_p(None)
         if sample_format not in ("f32", "s16"):
@@ -482,7 +490,12 @@ class UpolsFirEngine:
         self._fmt_code, self.dtype = _FORMATS[sample_format]
         self.gain = PCM16_GAIN if sample_format == "s16" else 1.0
         self.channels, self.chunk_size, self.device = int(channels), int(fir.chunk_size), int(device)
-        self.block = int(self._lib.adsp_upols_block_size())
+        sizes = self.block_sizes()
+        if block is None:
+            block = choose_uniform_block(fir, self.channels, sizes)
+        if int(block) not in sizes:
+            raise ValueError(f"block {block}: this build partitions into blocks of {sizes} samples")
+        self.block = int(block)
         self.partition = part = partition_uniform(fir, self.block, self.gain)
         self.max_steps = int(max_steps)
         cfg = _capi.AdspUpolsConfig(self.device, self.chunk_size, self.channels, self.block, part.n_partitions, part.delay, self._fmt_code,

@@ -40,13 +40,14 @@ def _exact(adsp, fir, x, fmt="f32"):
 # ---------------------------------------------------------------------------------------------------------------------
 # 1. Uniformly partitioned engines (csrc/adsp_upols.hip)
 # ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("block", [8192, 16384])
 @pytest.mark.parametrize("n,taps_len,latency,lookahead,channels,calls,max_steps", [
     (88200, 44099, 1, 22049, 3, [1, 1, 1], 1),        # Example4's low cut geometry (Example4.py:5, EffectFFTFilter.py:91-151), random taps
     (20000, 40000, 3, 20000, 9, [2, 1, 3], 2),        # kernel longer than two chunks, calls of several chunks, split into sub-calls
     (12000, 33000, 4, 16000, 67, [1, 2, 1, 1], 4),    # ragged channel count (the last XCD group is partly empty), odd delay (shift 0..3)
     (50000, 70001, 2, 12345, 1, [1, 1], 1),           # ONE channel, delay = 87655 -> 3 taps of kernel delay
 ])
-def test_upols_engine_matches_the_float64_direct_sum(adsp, n, taps_len, latency, lookahead, channels, calls, max_steps):
+def test_upols_engine_matches_the_float64_direct_sum(adsp, n, taps_len, latency, lookahead, channels, calls, max_steps, block):
     """Every output sample of every channel of a long-kernel stream against the float64 direct sum computed on the GPU
     (adsp_exact_*), and two channels against the oracle's direct_stream_convolution on the host; the same stream through
     PartitionedFirEngine (the round 1 - 4 form) agrees."""
@@ -54,8 +55,9 @@ def test_upols_engine_matches_the_float64_direct_sum(adsp, n, taps_len, latency,
     rng = np.random.default_rng(n + taps_len)
     taps = rng.standard_normal(taps_len) * np.hanning(taps_len) / np.sqrt(taps_len) * 3.0
     fir = adsp.FirStream(taps, n, latency_chunks=latency, lookahead=lookahead)
-    eng = adsp.UpolsFirEngine(fir, channels=channels, max_steps=max_steps)
-    assert eng.partition.n_partitions == -(-(taps_len + eng.partition.shift) // 8192) and eng.partition.delay % 4 == 0
+    eng = adsp.UpolsFirEngine(fir, channels=channels, max_steps=max_steps, block=block)
+    assert eng.block == block and adsp.UpolsFirEngine.block_sizes() == [8192, 16384]
+    assert eng.partition.n_partitions == -(-(taps_len + eng.partition.shift) // block) and eng.partition.delay % 4 == 0
     steps = sum(calls)
     g = torch.Generator(device="cuda").manual_seed(n)
     x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=g)
@@ -86,7 +88,8 @@ def test_upols_engine_matches_the_float64_direct_sum(adsp, n, taps_len, latency,
         pe.close()
 
 
-def test_upols_engine_int16_and_fused_effect(adsp):
+@pytest.mark.parametrize("block", [8192, 16384])
+def test_upols_engine_int16_and_fused_effect(adsp, block):
     """int16 PCM batches (the WAV front end, Utility.py:233-238 / :295-312, fused like the ADSP_FORMAT_S16 engines: <= 1 LSB against the
     exact engine's int16 stream) and a stateless effect on the output registers (EffectSaturator.py:27-49 after the long filter)."""
     import torch
@@ -96,7 +99,8 @@ def test_upols_engine_int16_and_fused_effect(adsp):
     taps = rng.standard_normal(taps_len) * np.hanning(taps_len) / np.sqrt(taps_len)
     fir = adsp.FirStream(taps, n, latency_chunks=2, lookahead=18000)
     pcm = torch.randint(-12000, 12000, (3, 5, n), device="cuda", dtype=torch.int16, generator=torch.Generator(device="cuda").manual_seed(9))
-    eng = adsp.UpolsFirEngine(fir, channels=5, sample_format="s16")
+    eng = adsp.UpolsFirEngine(fir, channels=5, sample_format="s16", block=block)
+    assert eng.block == block
     out = torch.empty_like(pcm)
     eng.apply_device(pcm, out, 3, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
@@ -106,7 +110,7 @@ def test_upols_engine_int16_and_fused_effect(adsp):
     eng.close()
     # fused saturator against the oracle's saturator applied to the exact stream
     x = torch.empty((2, 4, n), device="cuda").uniform_(-1, 1, generator=torch.Generator(device="cuda").manual_seed(10))
-    eng = adsp.UpolsFirEngine(adsp.FirStream(taps * 4.0, n, latency_chunks=2, lookahead=18000), channels=4)
+    eng = adsp.UpolsFirEngine(adsp.FirStream(taps * 4.0, n, latency_chunks=2, lookahead=18000), channels=4, block=block)
     eng.set_epilogue(adsp.CreateSaturator())
     y = torch.empty_like(x)
     eng.apply_device(x, y, 2, torch.cuda.current_stream().cuda_stream)
@@ -382,7 +386,7 @@ def test_upols_engine_randomised_shapes(adsp, seed):
     fmt = "s16" if seed % 4 == 3 else "f32"
     taps = rng.standard_normal(taps_len) * np.hanning(taps_len) / np.sqrt(taps_len) * 2.0
     fir = adsp.FirStream(taps, n, latency_chunks=latency, lookahead=lookahead)
-    eng = adsp.UpolsFirEngine(fir, channels=channels, sample_format=fmt, max_steps=int(rng.integers(1, 3)))
+    eng = adsp.UpolsFirEngine(fir, channels=channels, sample_format=fmt, max_steps=int(rng.integers(1, 3)), block=8192 if seed % 2 or fir.delay - fir.delay % 4 < 16384 else 16384)
     steps = sum(calls)
     g = torch.Generator(device="cuda").manual_seed(seed)
     if fmt == "s16":
@@ -397,7 +401,7 @@ def test_upols_engine_randomised_shapes(adsp, seed):
         pos += k
     torch.cuda.synchronize()
     t = _exact(adsp, fir, x, fmt)
-    what = f"seed {seed}: N={n} taps={taps_len} latency={latency} lookahead={lookahead} C={channels} calls={calls} {fmt}"
+    what = f"seed {seed}: N={n} taps={taps_len} latency={latency} lookahead={lookahead} C={channels} calls={calls} {fmt} B={eng.block}"
     if fmt == "s16":
         diff = (y.int() - t.int()).abs()
         assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) <= 0.01, what

@@ -74,6 +74,7 @@ class UpolsMirror:
 @pytest.mark.parametrize("n,taps_len,block,max_steps,calls", [
     (88200, 44099, 8192, 1, [1, 1, 1]),            # the reference's Example4 low cut
     (88200, 88197, 8192, 2, [1, 2, 1]),            # its EQ composite: 11 partitions
+    (88200, 88197, 16384, 1, [1, 1, 2]),           # the same on the larger block of the build: 6 partitions, history of one chunk
     (4096, 2500, 512, 3, [1, 3, 2, 5, 1]),         # small blocks: many blocks per call, calls of every length, sub-call splitting
     (1000, 1201, 256, 1, [1] * 7),                 # chunk not a multiple of the block, kernel longer than the chunk
     (520, 300, 256, 4, [2, 1, 4, 3]),              # history of several chunks (2 B > N)
@@ -115,3 +116,15 @@ def test_partition_uniform_of_the_reference_shapes():
         design.partition_uniform(design.FirStream(np.ones(40000), 30002), 8192)   # chunk not a multiple of 4
     with pytest.raises(ValueError):
         design.partition_uniform(design.FirStream(np.ones(40000), 4096), 8192)    # delayed by less than a block
+
+
+def test_block_size_policy():
+    """design.choose_uniform_block: the larger block only where the delay allows it and a call has blocks enough to fill the chip."""
+    lc = design.FirStream(design.lowcut_kernel(800, 44100, 88200), 88200)
+    assert design.choose_uniform_block(lc, 1) == 8192 and design.choose_uniform_block(lc, 64) == 8192
+    assert design.choose_uniform_block(lc, 1024) == 16384 and design.choose_uniform_block(lc, 4096) == 16384
+    short_delay = design.FirStream(np.ones(40000), 20000, latency_chunks=1, lookahead=8000)   # delayed by 12000 samples
+    assert design.choose_uniform_block(short_delay, 4096) == 8192
+    with pytest.raises(ValueError):
+        design.partition_uniform(short_delay, 16384)
+    assert design.partition_uniform(lc, 16384).n_partitions == 3 and design.partition_uniform(lc, 8192).n_partitions == 6

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--channels", type=int, nargs="+", default=[64, 1024])
     ap.add_argument("--calls", type=int, default=24)
     ap.add_argument("--only", default="", help="upols / partitioned: run just one engine kind (profiling)")
+    ap.add_argument("--block", type=int, default=0, help="block size of the uniformly partitioned engine (default: the largest the delay allows)")
     a = ap.parse_args()
     import torch
     import pyaudiodsptools_amd as adsp
@@ -34,7 +35,7 @@ def main():
             synth.fill_device(x, 1234, 0, 0, C, n, 4, "f32", 1.0, 0, torch.cuda.current_stream().cuda_stream)
             y = torch.empty((C, n), device=dev)
             res = {}
-            for kind, make in (("upols", lambda: adsp.UpolsFirEngine(fir, channels=C)), ("partitioned", lambda: adsp.PartitionedFirEngine(fir, channels=C))):
+            for kind, make in (("upols", lambda: adsp.UpolsFirEngine(fir, channels=C, block=a.block or None)), ("partitioned", lambda: adsp.PartitionedFirEngine(fir, channels=C))):
                 if a.only and a.only != kind:
                     continue
                 eng = make()
@@ -60,6 +61,7 @@ def main():
                              "passes" if kind == "partitioned" else "partitions": len(eng.engines) if kind == "partitioned" else eng.partition.n_partitions}
                 if kind == "upols":
                     res[kind]["delay_line_mib"] = round(eng.delay_line_bytes / 2 ** 20, 1)
+                    res[kind]["block"] = eng.block
                 eng.close()
                 del eng
                 torch.cuda.empty_cache()
