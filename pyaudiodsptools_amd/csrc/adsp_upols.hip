@@ -254,20 +254,20 @@ __global__ __launch_bounds__(PL::T, ADSP_UPOLS_MAC_WAVES) void upols_mac_kernel(
         s.za = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rz, lane16, (2 * h) * T * 16, 0));
         s.zb = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rz, lane16, (2 * h + 1) * T * 16, 0));
     };
+    // pair_op with the accumulation folded into its multiply-adds (16 instead of 20 instructions per pair)
+    auto pair_mac = [](float& xar, float& xai, float& xbr, float& xbi, float zar, float zai, float zbr, float zbi, const float2 c1, const float2 c2,
+                       const float2 c4) {
+        xar = fmaf(c2.y, zbi, fmaf(c2.x, zbr, fmaf(-c1.y, zai, fmaf(c1.x, zar, xar))));
+        xai = fmaf(-c2.x, zbi, fmaf(c2.y, zbr, fmaf(c1.y, zar, fmaf(c1.x, zai, xai))));
+        xbr = fmaf(c2.y, zai, fmaf(-c2.x, zar, fmaf(c4.y, zbi, fmaf(c4.x, zbr, xbr))));
+        xbi = fmaf(c2.y, zar, fmaf(c2.x, zai, fmaf(c4.x, zbi, fmaf(-c4.y, zbr, xbi))));
+    };
     auto multiply = [&](const Stage& s, int h) {
         const int r0 = 2 * h, r1 = 2 * h + 1;
-        float zar = s.za.x, zai = s.za.y, zbr = s.zb.x, zbi = s.zb.y;
-        pair_op(zar, zai, zbr, zbi, make_float2(s.f0.x, s.f0.y), make_float2(s.f0.z, s.f0.w), make_float2(s.f1.x, s.f1.y));
-        ar[NB * r0] += zar;
-        ai[NB * r0] += zai;
-        ar[NB * (R - 1 - r0) + 1] += zbr;
-        ai[NB * (R - 1 - r0) + 1] += zbi;
-        zar = s.za.z, zai = s.za.w, zbr = s.zb.z, zbi = s.zb.w;
-        pair_op(zar, zai, zbr, zbi, make_float2(s.f1.z, s.f1.w), make_float2(s.f2.x, s.f2.y), make_float2(s.f2.z, s.f2.w));
-        ar[NB * r1] += zar;
-        ai[NB * r1] += zai;
-        ar[NB * (R - 1 - r1) + 1] += zbr;
-        ai[NB * (R - 1 - r1) + 1] += zbi;
+        pair_mac(ar[NB * r0], ai[NB * r0], ar[NB * (R - 1 - r0) + 1], ai[NB * (R - 1 - r0) + 1], s.za.x, s.za.y, s.zb.x, s.zb.y, make_float2(s.f0.x, s.f0.y),
+                 make_float2(s.f0.z, s.f0.w), make_float2(s.f1.x, s.f1.y));
+        pair_mac(ar[NB * r1], ai[NB * r1], ar[NB * (R - 1 - r1) + 1], ai[NB * (R - 1 - r1) + 1], s.za.z, s.za.w, s.zb.z, s.zb.w, make_float2(s.f1.z, s.f1.w),
+                 make_float2(s.f2.x, s.f2.y), make_float2(s.f2.z, s.f2.w));
     };
     {
         const float2* z = block_of(0);
