@@ -725,6 +725,55 @@ def numpy_api_latency(n=4096, reps=1500):
     return (time.perf_counter() - t0) / reps * 1e6
 
 
+def long_kernel_figures(dev, channels=64, calls=24):
+    """Kernels longer than one transform in the reference's own shape (Example4.py:5, ModuleTestsGPU.py:35: chunk_size 88200 ->
+    CreateLowCutFilter 44 099 taps, CreateEQ3BandFFT 88 197 taps): one call per chunk on device-resident float32 batches through
+    make_engine (the uniformly partitioned engine, csrc/adsp_upols.hip), torch events over `calls` calls; checked against the float64
+    direct sum of adsp_exact on the last chunk of a fresh stream."""
+    import torch
+    import pyaudiodsptools_amd as adsp
+    from pyaudiodsptools_amd import design, synth as asynth
+    n, fs = 88200, 44100
+    s = torch.cuda.current_stream(dev).cuda_stream
+    out = {}
+    for name, taps in (("lowcut_44099_taps", design.lowcut_kernel(800, fs, n)), ("eq3_88197_taps", design.eq3_composite(100, 2, 700, -4, 8000, 5, fs, n))):
+        fir = adsp.FirStream(taps, n)
+        eng = adsp.make_engine(fir, channels=channels, device=dev.index)
+        x = torch.empty((4, channels, n), device=dev)
+        asynth.fill_device(x, 1234, 0, 0, channels, n, 4, "f32", 1.0, dev.index, s)
+        y = torch.empty((4, channels, n), device=dev)
+        eng.apply_device(x, y, 4, s)  # a fresh stream of four chunks: the parity sample
+        ex = adsp.ExactFirEngine(fir, channels=channels, device=dev.index)
+        t = torch.empty_like(y)
+        ex.apply_device(x, t, 4, s)
+        torch.cuda.synchronize(dev)
+        err = float((y[3] - t[3]).abs().max() / t[3].abs().max())
+        ex.close()
+        del t
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < 0.1:  # clock ramp
+            eng.apply_device(x[0], y[0], 1, s)
+            torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        runs = []
+        for _ in range(3):
+            e0.record()
+            for k in range(calls):
+                eng.apply_device(x[k % 4], y[k % 4], 1, s)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            runs.append(e0.elapsed_time(e1) * 1e-3 / calls)
+        per = sorted(runs)[1]
+        out[name] = {"engine": type(eng).__name__, "block": getattr(eng, "block", None), "partitions": getattr(getattr(eng, "partition", None), "n_partitions", None),
+                     "us_per_call": round(per * 1e6, 1), "msamples_s": round(channels * n / per / 1e6, 1),
+                     "roofline_frac": round(ALG_BYTES_PER_SAMPLE * channels * n / per / (HBM_PEAK_GBS * 1e9), 4), "max_rel_err_vs_float64_direct_sum": float(f"{err:.3e}")}
+        eng.close()
+        del eng, x, y
+        torch.cuda.empty_cache()
+    out["workload"] = f"{channels} channels x {n} samples per call (Example4.py:5), device-resident float32, median of 3 x {calls} calls"
+    return out
+
+
 def host_batch_figures(dev, gib=1.0, files=256, seconds_per_file=10):
     """The numpy API on REAL batches (host arrays in, host arrays out - the reference's contract, EffectFFTFilter.py:49-75, for many
     channels and chunks per call): FirEngine.apply_host on a `gib` GiB float32 batch (4096 channels x 4096 samples x 16 chunks) and
@@ -1102,9 +1151,14 @@ def main():
                 host_batches = host_batch_figures(dev) if not getattr(args, "small", False) and args.channels >= 1024 else None
             except Exception as exc:
                 host_batches = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            try:
+                long_kernels = long_kernel_figures(dev)
+            except Exception as exc:
+                long_kernels = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             latency = {"config3_eq3_2048_stereo_pairs_x_512": c3,
                        "numpy_api_apply_us_per_call": round(numpy_api_latency(), 2),
                        "numpy_api": host_batches,
+                       "long_kernels": long_kernels,
                        "note": "config 3 = CreateEQ3BandFFT(100,2,700,-4,8000,5) on 4096 mono channels (2048 stereo pairs) x 512 samples, one launch "
                                "per step (zero-copy ring); numpy API = CreateLowCutFilter(800).apply(float32[4096]) -> float32[4096], 1 channel, host "
                                "buffers (PCIe + launch bound, never `value`)"}

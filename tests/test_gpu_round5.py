@@ -224,6 +224,21 @@ def test_bench_n1_line_carries_configs_4_and_5_with_their_rooflines_and_the_orac
     assert d["data"].startswith("synthetic uniform(-1,1) float32")
 
 
+def test_bench_long_kernel_figures(adsp):
+    """The bench line's latency.long_kernels block (Example4's chunk 88200 through make_engine): on the uniformly partitioned engine,
+    within 1e-5 of the float64 direct sum."""
+    import sys
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    f = bench.long_kernel_figures(torch.device("cuda", 0), channels=6, calls=3)
+    for key, parts in (("lowcut_44099_taps", 6), ("eq3_88197_taps", 11)):
+        r = f[key]
+        assert r["engine"] == "UpolsFirEngine" and r["block"] == 8192 and r["partitions"] == parts
+        assert r["us_per_call"] > 0 and r["msamples_s"] > 0 and 0 <= r["max_rel_err_vs_float64_direct_sum"] <= 1e-5
+    assert "88200" in f["workload"]
+
+
 def test_bench_exits_non_zero_without_a_line_when_the_world_is_not_what_was_asked_for():
     """a job whose process group is smaller than --gpus N (or whose ranks ended up with different filters) must not print
     a line the driver could take for an N-GPU measurement.  Simulated on one GPU: a world of one that was told to expect two."""
