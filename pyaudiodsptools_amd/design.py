@@ -284,14 +284,15 @@ class UniformPartition:
 def choose_uniform_block(fir: "FirStream", channels: int, sizes=(8192, 16384)) -> int:
     """Block size of a uniformly partitioned engine: of the sizes the stream's delay allows (partition_uniform: delay >= block), the
     largest one once a call has enough blocks to fill the chip several times over - the multiply launch reads taps / B x 20 bytes per
-    output sample - and the smallest one below that, where more and shorter workgroups win (measured, profiles/r5_upols_block_16384.txt:
-    1024 channels x 88200: -3 % / -10 % with 16384; 64 channels: +16 % / +11 %)."""
+    output sample - and the smallest one below that, where more and shorter workgroups win (measured at chunk 88200, profiles/r5_upols_block_16384.txt
+    and r5_upols_block_threshold.txt: 16384 wins by 1 ... 10 % from 256 channels = 1378 blocks per call on, loses 11 ... 16 % at 64
+    channels = 344 blocks; the switch is at 1024 blocks per call)."""
     delay = int(fir.delay) - int(fir.delay) % 4
     valid = sorted(b for b in sizes if b <= delay)
     if not valid:
         return min(sizes)  # (partition_uniform raises for it)
     big = valid[-1]
-    return big if int(channels) * int(fir.chunk_size) >= 2048 * big else valid[0]
+    return big if int(channels) * int(fir.chunk_size) >= 1024 * big else valid[0]
 
 
 def partition_uniform(fir: FirStream, block: int, gain: float = 1.0) -> UniformPartition:

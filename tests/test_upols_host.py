@@ -122,7 +122,7 @@ def test_block_size_policy():
     """design.choose_uniform_block: the larger block only where the delay allows it and a call has blocks enough to fill the chip."""
     lc = design.FirStream(design.lowcut_kernel(800, 44100, 88200), 88200)
     assert design.choose_uniform_block(lc, 1) == 8192 and design.choose_uniform_block(lc, 64) == 8192
-    assert design.choose_uniform_block(lc, 1024) == 16384 and design.choose_uniform_block(lc, 4096) == 16384
+    assert design.choose_uniform_block(lc, 256) == 16384 and design.choose_uniform_block(lc, 4096) == 16384
     short_delay = design.FirStream(np.ones(40000), 20000, latency_chunks=1, lookahead=8000)   # delayed by 12000 samples
     assert design.choose_uniform_block(short_delay, 4096) == 8192
     with pytest.raises(ValueError):
