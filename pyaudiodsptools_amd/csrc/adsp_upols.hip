@@ -631,6 +631,11 @@ int adsp_upols_apply_device(adsp_upols* u, const void* d_in, void* d_out, int n_
     if (n_steps <= 0) return fail(ADSP_ERR_ARG, "n_steps must be positive");
     HIP_TRY(hipSetDevice(u->cfg.device_id));
     const size_t plane = u->plane_bytes();
+    {   // the second launch of a pair writes outputs while later blocks of the call still read their input windows
+        const char *i0 = static_cast<const char*>(d_in), *o0 = static_cast<const char*>(d_out);
+        const size_t span = (size_t)n_steps * plane;
+        if (i0 < o0 + span && o0 < i0 + span) return fail(ADSP_ERR_ARG, "d_in and d_out overlap: the partitioned engines do not run in place");
+    }
     for (int done = 0; done < n_steps;) {  // at most max_steps chunks per launch pair (the delay line is sized for that)
         const int n = n_steps - done < u->cfg.max_steps ? n_steps - done : u->cfg.max_steps;
         const int rc = upols_launch_pair(u, static_cast<const char*>(d_in) + (size_t)done * plane, static_cast<char*>(d_out) + (size_t)done * plane, n,

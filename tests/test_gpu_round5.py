@@ -139,6 +139,12 @@ def test_upols_raw_abi_refusals(adsp):
     cfg = _capi.AdspUpolsConfig(**ok)
     assert lib.adsp_upols_create(ctypes.byref(cfg), spec.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)) == 0
     assert lib.adsp_upols_apply_device(h, None, None, 1, None) != 0 and lib.adsp_upols_set_epilogue(h, 5, 0.4, 1e-4, 100.0) != 0
+    import torch
+    buf = torch.zeros((3, 2, 40000), device="cuda")   # in place, or overlapping by one chunk: refused
+    assert lib.adsp_upols_apply_device(h, ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(buf.data_ptr()), 2, None) != 0 and b"overlap" in lib.adsp_last_error()
+    assert lib.adsp_upols_apply_device(h, ctypes.c_void_p(buf[0].data_ptr()), ctypes.c_void_p(buf[1].data_ptr()), 2, None) != 0
+    assert lib.adsp_upols_apply_device(h, ctypes.c_void_p(buf[0].data_ptr()), ctypes.c_void_p(buf[2].data_ptr()), 1, None) == 0
+    torch.cuda.synchronize()
     lib.adsp_upols_destroy(h)
 
 
