@@ -430,3 +430,10 @@ def test_upols_engine_randomised_shapes(adsp, seed):
         scale = float(t.abs().max())
         assert scale > 0.05 and float((y - t).abs().max()) <= 1e-5 * scale, what
     eng.close()
+
+
+def test_graft_entry_smoke_runs():
+    """The driver's smoke(): one small invocation of the hot path (and of a long kernel) on cuda:0 against the oracle."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__
+    __graft_entry__.smoke()
