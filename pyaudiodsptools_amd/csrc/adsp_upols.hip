@@ -4,7 +4,7 @@
 // composite of 88 197 - more than the largest transform of fftconv_kernel.hpp (32768 real points) can take in one piece.  Round 1-4
 // cut such a kernel into slices of <= 14336 taps and ran ONE ENGINE PER SLICE over the same input (PartitionedFirEngine: P forward
 // and P inverse transforms per block, P reads of the input, P - 1 read-modify-writes of the output).  Here the kernel is cut into P
-// partitions of B taps each (B = 8192: the M = 8192 plan, the fastest per point), every input block of B samples is transformed ONCE,
+// partitions of B taps each (B = 8192: the M = 8192 plan, the fastest per point; or 16384), every input block of B samples is transformed ONCE,
 // its spectrum kept in a frequency-domain delay line in HBM, and an output block is
 //
 //     y_b = irfft( sum_p  X_{b-p} . H_p )[B .. 2B)          X_b = rfft( s[(b-1)B .. (b+1)B) )
@@ -17,9 +17,12 @@
 //                          last forward pass), 8 M bytes per block: the real-FFT split, the product with H_p and the re-packing
 //                          for the inverse are ONE 2x2 complex matrix per bin pair (fftconv_core.inc: pair_op), linear in
 //                          (Z[k], conj Z[M-k]), so the sum over partitions can be taken on the unsplit Z - and both partners of
-//                          a pair live in the same thread, in the delay line exactly as in the registers.
-//   upols_mac_kernel     : acc += pair_op_p(Z_{b-p}) for p = 0 .. P-1 (the pair tables of H_p are built like an ordinary engine's),
-//                          the inverse passes, the kept half [B, 2B) converted / passed through a fused effect and stored.
+//                          a pair live in the same thread; the delay line holds them in 16-byte units per lane, in the order the
+//                          second launch reads them.
+//   upols_mac_kernel     : acc += pair_op_p(Z_{b-p}) for p = 0 .. P-1 - the matrix of a pair formed in the kernel from 16 bytes of
+//                          table per pair and partition ((2s, 2d) of H_p's two bins) and the bin's twiddle - then the inverse passes,
+//                          the kept half [B, 2B) converted / passed through a fused effect and stored.  The launch is bound by what
+//                          the L2 delivers (tables + spectra: 24 P bytes per output sample, 88 % hits), not by issue or HBM.
 // The second launch reads what the first one wrote: the kernel boundary is the only synchronisation (no flags, no scopes).
 // Consecutive blocks of a channel share P - 1 spectra; blockIdx -> (channel, block) keeps them on one XCD (their L2).
 //
@@ -56,7 +59,7 @@ struct UpolsArgs {
     void* out;           // [n_steps][C][N]
     const void* zeros;   // N zero samples
     const float4* tw;    // pass twiddles of the plan
-    const float4* pair;  // [P] pair tables (complex form), pair_stride float4 each
+    const float4* pair;  // [P] tables of the regular pairs: [R][T] float4 = (2s, 2d) of pair r of thread t (adsp_upols_create), pair_stride float4 each
     const float2* pair0; // [P] tables of thread 0's self-paired butterflies, pair0_stride float2 each
     float2* zline;       // [C][R][PTS/2][T] float4: the delay line of forward-transformed blocks (two registers per unit: upols_forward_kernel)
     int ring_pos, ring_slots, C, N, nh, n_steps;
@@ -74,6 +77,41 @@ struct UpolsArgs {
 };
 
 namespace {
+
+// cos(pi x), sin(pi x) for 0 <= x < 1 at compile time (Taylor series about 0 of the argument folded into [-pi/2, pi/2]: 1e-16)
+__host__ __device__ constexpr double const_sin_small(double y) {
+    double term = y, sum = y;
+    for (int n = 1; n < 14; ++n) {
+        term *= -y * y / ((2 * n) * (2 * n + 1));
+        sum += term;
+    }
+    return sum;
+}
+__host__ __device__ constexpr double const_cos_small(double y) {
+    double term = 1.0, sum = 1.0;
+    for (int n = 1; n < 14; ++n) {
+        term *= -y * y / ((2 * n - 1) * (2 * n));
+        sum += term;
+    }
+    return sum;
+}
+constexpr double kPi = 3.14159265358979323846;
+__host__ __device__ constexpr double const_sin_pi(double x) { return x <= 0.5 ? const_sin_small(kPi * x) : const_sin_small(kPi * (1.0 - x)); }
+__host__ __device__ constexpr double const_cos_pi(double x) { return x <= 0.5 ? const_cos_small(kPi * x) : -const_cos_small(kPi * (1.0 - x)); }
+
+template <int R>
+struct HalfTurn {  // (cos, sin)(pi r / R), r = 0 .. R-1, as float literals of the kernel
+    float c[R], s[R];
+};
+template <int R>
+constexpr HalfTurn<R> half_turn() {
+    HalfTurn<R> t{};
+    for (int r = 0; r < R; ++r) {
+        t.c[r] = static_cast<float>(const_cos_pi(static_cast<double>(r) / R));
+        t.s[r] = static_cast<float>(const_sin_pi(static_cast<double>(r) / R));
+    }
+    return t;
+}
 
 template <class PL>
 __device__ __forceinline__ void upols_indices(int tid, int& ja, int& jb) {
@@ -234,26 +272,30 @@ __global__ __launch_bounds__(PL::T, ADSP_UPOLS_MAC_WAVES) void upols_mac_kernel(
     // ahead of the one being multiplied, across partition boundaries.  Lane 0's butterflies pair with THEMSELVES: what it
     // accumulates here is replaced by the sums above.
     struct Stage {
-        float4 f0, f1, f2;
+        float4 t0, t1;  // (2s, 2d) of the stage's two pairs: s = g1 + g2, d = g1 - g2 of pair_op's matrix (fftconv_core.inc), 16 bytes per pair
         float4 za, zb;  // (register NB 2h, register NB (2h+1)) and their partners: the delay line's units 2h, 2h+1
     };
-    constexpr int kStages = R / 2, kAhead = ADSP_UPOLS_AHEAD;
+    constexpr int kStages = R / 2, kAhead = PL::P > 32 ? 2 : ADSP_UPOLS_AHEAD;  // (64 points per thread: 128 accumulators leave room for two stages)
     static_assert(kStages % kAhead == 0, "the stage ring is indexed at compile time");
     Stage st[kAhead];
     // buffer loads of 16 bytes per lane (the vector-memory path takes ~7 ns per wave instruction whatever its width: micro/tcp_rate.hip):
-    // one lane offset, everything else is a scalar offset - 40 global addresses per partition would otherwise be kept in registers
+    // one lane offset, everything else is a scalar offset - 32 global addresses per partition would otherwise be kept in registers
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     auto as_f4 = [](v4u u) { return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)); };
     const int lane16 = tid * 16;
     auto request = [&](Stage& s, const float2* z, const float4* tab, int h) {
-        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(tab), 0, kStages * 3 * T * 16, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(tab), 0, R * T * 16, 0x00020000);
         const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(z), 0, static_cast<int>(kSlot) * 8, 0x00020000);
-        s.f0 = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rt, lane16, (h * 3 + 0) * T * 16, 0));
-        s.f1 = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rt, lane16, (h * 3 + 1) * T * 16, 0));
-        s.f2 = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rt, lane16, (h * 3 + 2) * T * 16, 0));
+        s.t0 = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rt, lane16, (2 * h) * T * 16, 0));
+        s.t1 = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rt, lane16, (2 * h + 1) * T * 16, 0));
         s.za = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rz, lane16, (2 * h) * T * 16, 0));
         s.zb = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rz, lane16, (2 * h + 1) * T * 16, 0));
     };
+    // The matrix entries c1 = 2s + 2d Re(wc), c2 = -2i d Im(wc), c4 = 2s - 2d Re(wc) are formed here: the twiddle wc = -i exp(-i pi k / M) of
+    // bin k = tid + (M / R) r does not depend on the partition - (cos, sin)(pi tid / M) in two registers, (cos, sin)(pi r / R) literals - so the
+    // tables carry 16 instead of 24 bytes per pair and partition (the launch is bound by what the L2 delivers, not by the 10 instructions).
+    float c0, s0;
+    sincospif(static_cast<float>(tid) / static_cast<float>(PL::M), &s0, &c0);
     // pair_op with the accumulation folded into its multiply-adds (16 instead of 20 instructions per pair)
     auto pair_mac = [](float& xar, float& xai, float& xbr, float& xbi, float zar, float zai, float zbr, float zbi, const float2 c1, const float2 c2,
                        const float2 c4) {
@@ -262,12 +304,18 @@ __global__ __launch_bounds__(PL::T, ADSP_UPOLS_MAC_WAVES) void upols_mac_kernel(
         xbr = fmaf(c2.y, zai, fmaf(-c2.x, zar, fmaf(c4.y, zbi, fmaf(c4.x, zbr, xbr))));
         xbi = fmaf(c2.y, zar, fmaf(c2.x, zai, fmaf(c4.x, zbi, fmaf(-c4.y, zbr, xbi))));
     };
+    auto pair_of = [&](int r, const float4 sd, float zar, float zai, float zbr, float zbi) {
+        constexpr HalfTurn<R> turn = half_turn<R>();
+        const float cr = turn.c[r], sr = turn.s[r];
+        const float wr = -fmaf(c0, sr, s0 * cr), wi = -fmaf(c0, cr, -s0 * sr);  // -sin, -cos of pi k / M
+        const float2 c1 = make_float2(fmaf(sd.z, wr, sd.x), fmaf(sd.w, wr, sd.y));
+        const float2 c4 = make_float2(fmaf(-sd.z, wr, sd.x), fmaf(-sd.w, wr, sd.y));
+        const float2 c2 = make_float2(sd.w * wi, -sd.z * wi);
+        pair_mac(ar[NB * r], ai[NB * r], ar[NB * (R - 1 - r) + 1], ai[NB * (R - 1 - r) + 1], zar, zai, zbr, zbi, c1, c2, c4);
+    };
     auto multiply = [&](const Stage& s, int h) {
-        const int r0 = 2 * h, r1 = 2 * h + 1;
-        pair_mac(ar[NB * r0], ai[NB * r0], ar[NB * (R - 1 - r0) + 1], ai[NB * (R - 1 - r0) + 1], s.za.x, s.za.y, s.zb.x, s.zb.y, make_float2(s.f0.x, s.f0.y),
-                 make_float2(s.f0.z, s.f0.w), make_float2(s.f1.x, s.f1.y));
-        pair_mac(ar[NB * r1], ai[NB * r1], ar[NB * (R - 1 - r1) + 1], ai[NB * (R - 1 - r1) + 1], s.za.z, s.za.w, s.zb.z, s.zb.w, make_float2(s.f1.z, s.f1.w),
-                 make_float2(s.f2.x, s.f2.y), make_float2(s.f2.z, s.f2.w));
+        pair_of(2 * h, s.t0, s.za.x, s.za.y, s.zb.x, s.zb.y);
+        pair_of(2 * h + 1, s.t1, s.za.z, s.za.w, s.zb.z, s.zb.w);
     };
     {
         const float2* z = block_of(0);
@@ -565,16 +613,29 @@ int adsp_upols_create(const adsp_upols_config* cfg, const float* spectra, adsp_u
     if ((err = hipMalloc(&u->tw, tw.size() * sizeof(float4))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
     if ((err = hipMemcpy(u->tw, tw.data(), tw.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess)
         return bail(fail(ADSP_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(err)));
+    // per partition: tab0 = the (c1, c2, c4) entries of thread 0's self-paired butterflies, built like an engine's (build_pair_tables);
+    // the regular pairs as (2s, 2d) - pair r of thread t is the bins k = t + (M / R) r and M - k (table_build.hpp: pair_entry):
+    //   g1 = H[k] / 4M, g2 = conj(H[M-k]) / 4M, s = g1 + g2, d = g1 - g2;  the kernel forms c1, c2, c4 from them and the bin's twiddle
     std::vector<float4> tab, all;
     std::vector<float2> tab0, all0;
+    const int RR = pl.rad[pl.NP - 1], D = kB / RR, T = pl.T;
+    if (pl.XL || pl.P / RR != 2) return bail(fail(ADSP_ERR_STATE, "internal: the partitioned engines run in-register pairing plans with one pair of butterflies per thread"));
+    u->pair_stride = RR * T;
+    all.resize((size_t)cfg->n_partitions * u->pair_stride);
     for (int p = 0; p < cfg->n_partitions; ++p) {
-        build_pair_tables<float, float>(pl, kB, spectra + (size_t)p * 2 * (kB + 1), false, tab, tab0);
-        if (p == 0) {
-            u->pair_stride = (int)tab.size();
-            u->pair0_stride = (int)tab0.size();
-        }
-        all.insert(all.end(), tab.begin(), tab.end());
+        const float* H = spectra + (size_t)p * 2 * (kB + 1);
+        build_pair_tables<float, float>(pl, kB, H, false, tab, tab0);
+        if (p == 0) u->pair0_stride = (int)tab0.size();
         all0.insert(all0.end(), tab0.begin(), tab0.end());
+        const double sc = 1.0 / (4.0 * (double)kB);
+        for (int r = 0; r < RR; ++r)
+            for (int t = 0; t < T; ++t) {
+                const int k = t + D * r;
+                const double g1r = (double)H[2 * k] * sc, g1i = (double)H[2 * k + 1] * sc;
+                const double g2r = (double)H[2 * (kB - k)] * sc, g2i = -(double)H[2 * (kB - k) + 1] * sc;
+                all[(size_t)p * u->pair_stride + (size_t)r * T + t] =
+                    make_float4((float)(2.0 * (g1r + g2r)), (float)(2.0 * (g1i + g2i)), (float)(2.0 * (g1r - g2r)), (float)(2.0 * (g1i - g2i)));
+            }
     }
     if ((err = hipMalloc(&u->pair, all.size() * sizeof(float4))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
     if ((err = hipMalloc(&u->pair0, all0.size() * sizeof(float2))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));

@@ -282,17 +282,18 @@ class UniformPartition:
 
 
 def choose_uniform_block(fir: "FirStream", channels: int, sizes=(8192, 16384)) -> int:
-    """Block size of a uniformly partitioned engine: of the sizes the stream's delay allows (partition_uniform: delay >= block), the
-    largest one once a call has enough blocks to fill the chip several times over - the multiply launch reads taps / B x 20 bytes per
-    output sample - and the smallest one below that, where more and shorter workgroups win (measured at chunk 88200, profiles/r5_upols_block_16384.txt
-    and r5_upols_block_threshold.txt: 16384 wins by 1 ... 10 % from 256 channels = 1378 blocks per call on, loses 11 ... 16 % at 64
-    channels = 344 blocks; the switch is at 1024 blocks per call)."""
+    """Block size of a uniformly partitioned engine.  Per output sample the multiply launch reads taps / B x 16 bytes of tables and
+    8 of spectra, so a larger block pays for kernels of many partitions - where the stream's delay allows it (partition_uniform:
+    delay >= block) and a call has blocks enough to fill the chip several times over; more and shorter workgroups win everywhere
+    else.  Measured at chunk 88200 (profiles/r5_upols_compact_tables.txt, r5_upols_block_16384.txt, r5_upols_block_threshold.txt): the
+    EQ composite (11 partitions of 8192) at 1024 channels -3 % on blocks of 16384, the low cut (6 partitions) +5 %, 64 channels +19 %."""
     delay = int(fir.delay) - int(fir.delay) % 4
     valid = sorted(b for b in sizes if b <= delay)
     if not valid:
         return min(sizes)  # (partition_uniform raises for it)
-    big = valid[-1]
-    return big if int(channels) * int(fir.chunk_size) >= 1024 * big else valid[0]
+    small, big = valid[0], valid[-1]
+    many_partitions = -(-(len(fir.taps) + int(fir.delay) % 4) // small) >= 10
+    return big if many_partitions and int(channels) * int(fir.chunk_size) >= 1024 * big else small
 
 
 def partition_uniform(fir: FirStream, block: int, gain: float = 1.0) -> UniformPartition:

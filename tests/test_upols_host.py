@@ -119,11 +119,14 @@ def test_partition_uniform_of_the_reference_shapes():
 
 
 def test_block_size_policy():
-    """design.choose_uniform_block: the larger block only where the delay allows it and a call has blocks enough to fill the chip."""
-    lc = design.FirStream(design.lowcut_kernel(800, 44100, 88200), 88200)
-    assert design.choose_uniform_block(lc, 1) == 8192 and design.choose_uniform_block(lc, 64) == 8192
-    assert design.choose_uniform_block(lc, 256) == 16384 and design.choose_uniform_block(lc, 4096) == 16384
-    short_delay = design.FirStream(np.ones(40000), 20000, latency_chunks=1, lookahead=8000)   # delayed by 12000 samples
+    """design.choose_uniform_block: the larger block only for kernels of many partitions, where the delay allows it and a call has blocks
+    enough to fill the chip."""
+    lc = design.FirStream(design.lowcut_kernel(800, 44100, 88200), 88200)                      # 6 partitions of 8192
+    eq = design.FirStream(design.eq3_composite(100, 2, 700, -4, 8000, 5, 44100, 88200), 88200)  # 11
+    assert all(design.choose_uniform_block(lc, c) == 8192 for c in (1, 64, 1024, 4096))
+    assert design.choose_uniform_block(eq, 1) == 8192 and design.choose_uniform_block(eq, 64) == 8192
+    assert design.choose_uniform_block(eq, 256) == 16384 and design.choose_uniform_block(eq, 4096) == 16384
+    short_delay = design.FirStream(np.ones(100000), 20000, latency_chunks=1, lookahead=8000)   # delayed by 12000 samples
     assert design.choose_uniform_block(short_delay, 4096) == 8192
     with pytest.raises(ValueError):
         design.partition_uniform(short_delay, 16384)
