@@ -711,13 +711,16 @@ def live_figures(args, fir, dev, alg_bytes, channels, chunk, steps=4096, ring=25
     return res
 
 
-def numpy_api_latency(n=4096, reps=1500):
+def numpy_api_latency(n=4096, reps=1500, warm=200, make="lowcut"):
     """What a drop-in user of the reference API sees: dev.apply(numpy chunk) -> numpy chunk, one mono channel."""
     import pyaudiodsptools_amd as adsp
     adsp.config.initialize(44100, n)
-    dev = adsp.CreateLowCutFilter(800)
+    dev = adsp.CreateLowCutFilter(800) if make == "lowcut" else adsp.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5)
     x = np.random.default_rng(0).uniform(-1, 1, n).astype(np.float32)
-    for _ in range(200):
+    t_warm = time.perf_counter()
+    for _ in range(warm):
+        dev.apply(x)
+    while time.perf_counter() - t_warm < 0.25:  # (a device whose design took seconds on the host starts on an idle GPU: clock ramp)
         dev.apply(x)
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -771,6 +774,12 @@ def long_kernel_figures(dev, channels=64, calls=24):
         del eng, x, y
         torch.cuda.empty_cache()
     out["workload"] = f"{channels} channels x {n} samples per call (Example4.py:5), device-resident float32, median of 3 x {calls} calls"
+    # ... and what Example4 itself does: ONE mono chunk of 88200 samples through the drop-in device, numpy in, numpy out
+    try:
+        out["numpy_api_1ch_us_per_call"] = {"CreateLowCutFilter(800)": round(numpy_api_latency(n, reps=60, warm=8), 1),
+                                            "CreateEQ3BandFFT(100,2,700,-4,8000,5)": round(numpy_api_latency(n, reps=60, warm=8, make="eq3"), 1)}
+    except Exception as exc:
+        out["numpy_api_1ch_us_per_call"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
     return out
 
 
