@@ -46,6 +46,7 @@ def _exact(adsp, fir, x, fmt="f32"):
     (20000, 40000, 3, 20000, 9, [2, 1, 3], 2),        # kernel longer than two chunks, calls of several chunks, split into sub-calls
     (12000, 33000, 4, 16000, 67, [1, 2, 1, 1], 4),    # ragged channel count (the last XCD group is partly empty), odd delay (shift 0..3)
     (50000, 70001, 2, 12345, 1, [1, 1], 1),           # ONE channel, delay = 87655 -> 3 taps of kernel delay
+    (50000, 300001, 7, 20000, 2, [1, 2], 1),          # a kernel of six chunks: 37 / 19 partitions, a delay line of 87 / 45 blocks
 ])
 def test_upols_engine_matches_the_float64_direct_sum(adsp, n, taps_len, latency, lookahead, channels, calls, max_steps, block):
     """Every output sample of every channel of a long-kernel stream against the float64 direct sum computed on the GPU
@@ -71,7 +72,7 @@ def test_upols_engine_matches_the_float64_direct_sum(adsp, n, taps_len, latency,
     t = _exact(adsp, fir, x)
     scale = float(t.abs().max())
     assert scale > 0.1 and float((y - t).abs().max()) <= 1e-5 * scale, float((y - t).abs().max()) / scale
-    for c in sorted({0, channels - 1}):
+    for c in sorted({0, channels - 1}) if taps_len <= 100000 else ():   # (the host's direct sum of the longest kernel would take minutes)
         ref = orc().direct_stream_convolution(taps, x[:, c].reshape(-1).cpu().numpy(), n, latency, lookahead)
         assert_parity(y[:, c].reshape(-1).cpu().numpy(), ref, what=f"oracle channel {c}")
     # the host path on a fresh stream, and reset
@@ -79,7 +80,7 @@ def test_upols_engine_matches_the_float64_direct_sum(adsp, n, taps_len, latency,
     yh = eng.apply_host(x[:calls[0]].cpu().numpy())
     assert np.abs(yh - y[:calls[0]].cpu().numpy()).max() <= 2e-6 * scale
     eng.close()
-    if channels <= 9:
+    if channels <= 9 and taps_len <= 100000:
         pe = adsp.PartitionedFirEngine(fir, channels=channels)
         yp = torch.empty_like(x)
         pe.apply_device(x, yp, steps, s)
