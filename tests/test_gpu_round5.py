@@ -46,7 +46,7 @@ def _exact(adsp, fir, x, fmt="f32"):
     (20000, 40000, 3, 20000, 9, [2, 1, 3], 2),        # kernel longer than two chunks, calls of several chunks, split into sub-calls
     (12000, 33000, 4, 16000, 67, [1, 2, 1, 1], 4),    # ragged channel count (the last XCD group is partly empty), odd delay (shift 0..3)
     (50000, 70001, 2, 12345, 1, [1, 1], 1),           # ONE channel, delay = 87655 -> 3 taps of kernel delay
-    (50000, 300001, 7, 20000, 2, [1, 2], 1),          # a kernel of six chunks: 37 / 19 partitions, a delay line of 87 / 45 blocks
+    (50000, 300001, 1, 20000, 2, [1, 2, 1], 1),       # a kernel of six chunks: 37 / 19 partitions
 ])
 def test_upols_engine_matches_the_float64_direct_sum(adsp, n, taps_len, latency, lookahead, channels, calls, max_steps, block):
     """Every output sample of every channel of a long-kernel stream against the float64 direct sum computed on the GPU
