@@ -346,3 +346,14 @@ def test_traffic_stamp_follows_the_kernel_code_not_its_comments(tmp_path):
         import warnings
         warnings.warn("profiles/traffic.json was measured on other kernel sources than this tree's: re-run tools/sessions/r4_session25.sh "
                       "and tools/update_traffic.py before quoting a traffic figure")
+
+
+def test_upols_block_sizes_are_reported_without_a_gpu():
+    """adsp_upols_block_sizes: count with a NULL array, the ascending sizes otherwise; the smallest is adsp_upols_block_size()."""
+    from pyaudiodsptools_amd import _capi
+    lib = _capi.load()
+    assert lib.adsp_upols_block_sizes(None, 0) == 2
+    sizes = (ctypes.c_int * 4)()
+    assert lib.adsp_upols_block_sizes(sizes, 4) == 2 and list(sizes[:2]) == [8192, 16384] and lib.adsp_upols_block_size() == 8192
+    one = (ctypes.c_int * 1)()
+    assert lib.adsp_upols_block_sizes(one, 1) == 2 and one[0] == 8192   # a short array is filled as far as it goes
