@@ -24,6 +24,16 @@ from .effects import Effect
 from .engine import FirEngine, make_engine
 
 
+def _is_device_tensor(x):
+    """A torch tensor that lives on a GPU (the stand-in for the cupy arrays of the reference's *GPU twins)."""
+    return type(x).__module__.split(".")[0] == "torch" and bool(getattr(x, "is_cuda", False))
+
+
+def _host(a):
+    """numpy view / copy of whatever a device keeps as history: numpy arrays as they are, device tensors copied back."""
+    return a.detach().cpu().numpy() if _is_device_tensor(a) else a
+
+
 class _FFTDevice:
     """Shared plumbing of the three devices."""
 
@@ -54,6 +64,8 @@ class _FFTDevice:
         """One chunk in, the previous chunk (filtered) out: float32 array of config.chunk_size samples."""
         if self.channels != 1:
             raise ValueError("this device holds several channels; use apply_batch(x[channels, chunk])")
+        if _is_device_tensor(float32_array_input):
+            return self._apply_device_tensor(float32_array_input)
         flat = np.concatenate((float32_array_input,), axis=None)  # same flattening as the reference
         if flat.size != self._n:
             raise ValueError(f"operands could not be broadcast together: chunk has {flat.size} samples, "
@@ -63,6 +75,23 @@ class _FFTDevice:
         self._rotate(float32_array_input)
         self._last_output = y.reshape(self._n)
         return y.reshape(self._n)
+
+    def _apply_device_tensor(self, x):
+        """The *GPU twins' call (EffectFFTFilterGPU.py:54-78, EffectEQ3BandFFTGPU.py:161-215: device array in, device array out - Example4.py:19)
+        with a torch tensor where the reference takes a cupy array: no host copy in either direction, the launch goes on torch's current
+        stream of the tensor's device and the result is a fresh float32 tensor there."""
+        import torch
+        if x.numel() != self._n:
+            raise ValueError(f"operands could not be broadcast together: chunk has {x.numel()} samples, "
+                             f"config.chunk_size was {self._n} when this device was created")
+        if x.device.index != self.engine.device:
+            raise ValueError(f"the chunk lives on GPU {x.device.index}, this device was created on GPU {self.engine.device}")
+        xin = x.detach().reshape(self._n).to(torch.float32).contiguous()
+        y = torch.empty(self._n, device=x.device, dtype=torch.float32)
+        self.engine.apply_device(xin, y, 1, torch.cuda.current_stream(x.device).cuda_stream)
+        self._rotate(x)
+        self._last_output = y
+        return y
 
     def apply_batch(self, chunk_batch):
         """[channels, N] (one step) or [steps, channels, N] float32 -> same shape."""
@@ -80,7 +109,7 @@ class _FFTDevice:
 
     def _concatenated_inputs(self):
         """The 3N-sample buffer the reference transforms: chunks k-2, k-1, k flattened (EffectFFTFilter.py:67-68)."""
-        return np.concatenate((self.float32_array_input_3, self.float32_array_input_2, self.float32_array_input_1), axis=None)
+        return np.concatenate((_host(self.float32_array_input_3), _host(self.float32_array_input_2), _host(self.float32_array_input_1)), axis=None)
 
     def _cut_filter_filtered_signal(self):
         # EffectFFTFilter.py:39 (zeros(3N) until the first apply), :67-73 (afterwards the sliced inverse transform: N complex values
@@ -88,7 +117,7 @@ class _FFTDevice:
         # part - rounding noise of the reference's complex transform - is exactly zero.
         if self._last_output is None:
             return np.zeros(self._n * 3)
-        return np.asarray(self._last_output).astype(np.complex128)
+        return np.asarray(_host(self._last_output)).astype(np.complex128)
 
 
 class CreateHighCutFilter(_FFTDevice):
@@ -176,7 +205,8 @@ class CreateEQ3BandFFT(_FFTDevice):
         return reference_spectrum_3n(self._bands["mid_highpass"], self._n)
 
 
-# The reference's cupy twins (EffectFFTFilterGPU.py, EffectEQ3BandFFTGPU.py) have the same surface.
+# The reference's cupy twins (EffectFFTFilterGPU.py, EffectEQ3BandFFTGPU.py) have the same surface; a GPU-resident chunk (a torch tensor,
+# where the reference takes a cupy array) stays on the GPU through apply() - with either name.
 CreateHighCutFilterGPU = CreateHighCutFilter
 CreateLowCutFilterGPU = CreateLowCutFilter
 CreateEQ3BandFFTGPU = CreateEQ3BandFFT

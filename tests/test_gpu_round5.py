@@ -438,3 +438,25 @@ def test_graft_entry_smoke_runs():
     sys.path.insert(0, ROOT)
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+@pytest.mark.parametrize("n", [4096, 88200])
+def test_gpu_twins_keep_a_device_resident_chunk_on_the_gpu(adsp, n):
+    """Example4.py:9-21 / ModuleTestsGPU.py:58: the *GPU classes are fed device arrays (cupy there, torch tensors here) and return device
+    arrays; the stream must be the one the numpy call produces, and the inspectable attributes still read back."""
+    import torch
+    adsp.config.initialize(44100, n)
+    x = seeded_stream(n, 4 * n)
+    for make in (lambda: adsp.CreateLowCutFilterGPU(800), lambda: adsp.CreateEQ3BandFFTGPU(100, 2, 700, -4, 8000, 5)):
+        host_dev, gpu_dev = make(), make()
+        want = np.concatenate([host_dev.apply(x[i * n:(i + 1) * n]) for i in range(4)])
+        xd = torch.from_numpy(x).cuda()
+        outs = [gpu_dev.apply(xd[i * n:(i + 1) * n]) for i in range(4)]
+        assert all(isinstance(o, torch.Tensor) and o.is_cuda and o.dtype == torch.float32 and o.shape == (n,) for o in outs)
+        got = torch.cat(outs).cpu().numpy()
+        assert np.array_equal(got, want)                      # the same kernels on the same data: bit for bit
+        assert np.array_equal(gpu_dev.original_signal, host_dev.original_signal) if hasattr(gpu_dev, "original_signal") else True
+        assert np.asarray(gpu_dev.filtered_signal).shape == np.asarray(host_dev.filtered_signal).shape
+        with pytest.raises(ValueError):
+            gpu_dev.apply(xd[:n - 4])
+    adsp.config.initialize(44100, 4096)
