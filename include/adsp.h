@@ -41,7 +41,7 @@ extern "C" {
 #define ADSP_API
 #endif
 
-#define ADSP_ABI_VERSION 10
+#define ADSP_ABI_VERSION 11
 #define ADSP_MAX_HISTORY 8
 
 typedef enum adsp_status {
@@ -228,6 +228,18 @@ ADSP_API int adsp_effect_host(int device_id, int effect, float p0, float p1, flo
  * array of k device (adsp_mix_device) or host (adsp_mix_host) pointers; out may alias an input when k <= 8. */
 ADSP_API int adsp_mix_device(int device_id, const float* const* d_inputs, int k, int clip, float* d_out, size_t n, void* stream);
 ADSP_API int adsp_mix_host(int device_id, const float* const* inputs, int k, int clip, float* out, size_t n);
+
+/* Non-finite inputs as the reference treats them.  The reference transforms chunks k-2, k-1, k as ONE 3N-point buffer
+ * (EffectFFTFilter.py:67-72, EffectEQ3BandFFT.py:175-179), so one NaN / Inf sample turns the WHOLE returned chunk into NaN in
+ * the call that takes it and in the two calls after it (tests/golden/kat_nonfinite.npz).  The engines' overlap-save blocks
+ * poison only the blocks whose window holds the sample - a subset of those three chunks, a superset of the FIR's support.
+ * This pass, launched on `stream` behind the filter call that turned d_in into d_out ([n_channels][chunk_size] float32 each),
+ * restores the reference's behaviour per channel: it scans the new chunk, records the finding in slot `slot` (= call index
+ * modulo 3) of the channel's flag ring d_flags[n_channels][3] (caller-owned device memory, zero before the first call) and
+ * overwrites the channel's output chunk with NaN when any of its three slots is set.  The drop-in classes' apply() on
+ * device-resident chunks uses it; host chunks are checked on the host. */
+ADSP_API int adsp_nonfinite_guard(int device_id, const float* d_in, float* d_out, int n_channels, int chunk_size, unsigned* d_flags,
+                                  int slot, void* stream);
 
 /* Output mode of a float32 engine.  0: overwrite the output buffer (default).  1: ADD the filtered samples to what
  * the buffer holds - later parts of a partitioned convolution (a kernel longer than one transform is split into parts,
@@ -507,7 +519,7 @@ ADSP_API int adsp_exact_apply_host(adsp_exact* fir, const void* in, void* out, i
  * Uniformly partitioned engines (round 5): streaming FIRs LONGER than one transform - the reference's own GPU example runs
  * chunk_size 88200 (Example4.py:5, ModuleTestsGPU.py:35: CreateLowCutFilter -> 44 099 taps, CreateEQ3BandFFT -> 88 197).
  *     out[tau] = y[tau - delay],   y = taps (*) s   (zero history),   taps cut into P partitions of B taps, B one of
- *     adsp_upols_block_sizes() (8192, 16384: per output sample the second launch reads P x 20 bytes - the largest B <= delay is the fastest)
+ *     adsp_upols_block_sizes() (8192, 16384: per output sample the second launch reads P x 16 bytes - 8 of table, 8 of spectrum)
  * Every input block of B samples is transformed ONCE (2B-point real FFT), its spectrum kept in a frequency-domain delay line in HBM;
  * an output block is ONE inverse transform of sum_p X_{b-p} H_p.  Two launches per call (forward transforms; multiply-accumulate +
  * inverse + store), each over every (channel, block) at once - instead of one full engine pass per kernel slice.
@@ -518,7 +530,9 @@ ADSP_API int adsp_exact_apply_host(adsp_exact* fir, const void* in, void* out, i
  *   max_steps: chunks one pair of launches covers at most (longer calls are split); sizes the delay line:
  *             (ceil((max_steps * chunk_size + delay) / B) + n_partitions + 3) blocks of 8 B bytes per channel.
  * A stateless fused effect (ADSP_EFFECT_* except the tremolo; float32 engines) is applied to the output registers.
- * Calls of one engine must be ordered on one stream (or synchronised in between): the second launch reads what the first wrote.
+ * Calls of one engine are ordered by the library whatever streams they are given (a call on another stream than the previous one
+ * first waits for an event recorded behind the previous call's launches); one host thread per engine at a time.
+ * After every call the engine keeps only the LAST 2B samples of the input it was given (no later window reaches further back).
  * ------------------------------------------------------------------------------------------------------------- */
 typedef struct adsp_upols adsp_upols; /* opaque */
 typedef struct adsp_upols_config {
@@ -541,6 +555,15 @@ ADSP_API int adsp_upols_info(const adsp_upols* fir, int* history_chunks, int* de
 /* d_in / d_out: device [n_steps][n_channels][chunk_size], NOT aliased; asynchronous on `stream` */
 ADSP_API int adsp_upols_apply_device(adsp_upols* fir, const void* d_in, void* d_out, int n_steps, void* stream);
 ADSP_API int adsp_upols_apply_host(adsp_upols* fir, const void* in, void* out, int n_steps);
+/* wait until everything this engine has launched - on `stream` or, if its last call went elsewhere, there - has finished */
+ADSP_API int adsp_upols_synchronize(adsp_upols* fir, void* stream);
+/* Checkpoint / resume (the reference's whole state is its two previous chunks, EffectFFTFilter.py:40-42 - a partitioned
+ * engine's is the transformed past): get_state drains the device and copies counters, input ring and frequency-domain delay line
+ * into `state` (adsp_upols_state_bytes bytes: ~8 B per sample of delay line, 1.75 MiB per channel for Example4's low cut); set_state
+ * on an engine of the same configuration continues the stream bit for bit.  A state of another shape is refused. */
+ADSP_API int adsp_upols_state_bytes(const adsp_upols* fir, size_t* bytes);
+ADSP_API int adsp_upols_get_state(adsp_upols* fir, void* state, size_t capacity);
+ADSP_API int adsp_upols_set_state(adsp_upols* fir, const void* state, size_t bytes);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Counter-based synthetic input: sample (channel c, absolute index t) is a pure function of (seed, c, t) -

@@ -10,6 +10,7 @@ runs in hand-written HIP kernels behind the C ABI of include/adsp.h.  Importing 
 not need a GPU; creating a device does.
 """
 from . import config
+from ._capi import AdspError
 from .design import FirStream
 from .devices import (CreateEQ3BandFFT, CreateEQ3BandFFTGPU, CreateHighCutFilter, CreateHighCutFilterGPU,
                       CreateLowCutFilter, CreateLowCutFilterGPU, fuse)
@@ -22,7 +23,7 @@ from . import wavio as Utility
 from .wavio import (CombineChunks, MakeChunks, MonoWavToNumpy16BitInt, MonoWavToNumpyFloat, NumpyFloatToWav,
                     StereoWavToNumpyFloat, WavBank)
 
-__all__ = ["config", "CreateHighCutFilter", "CreateLowCutFilter", "CreateEQ3BandFFT", "CreateHighCutFilterGPU",
+__all__ = ["config", "AdspError", "CreateHighCutFilter", "CreateLowCutFilter", "CreateEQ3BandFFT", "CreateHighCutFilterGPU",
            "CreateLowCutFilterGPU", "CreateEQ3BandFFTGPU", "FirEngine", "ExactFirEngine", "PartitionedFirEngine", "UpolsFirEngine", "make_engine", "FirStream", "fuse", "Utility", "MakeChunks",
            "CombineChunks", "MonoWavToNumpyFloat", "MonoWavToNumpy16BitInt", "StereoWavToNumpyFloat", "NumpyFloatToWav",
            "WavBank", "CreateSoftClipper", "CreateHardDistortion", "CreateSaturator", "VolumeChange", "CreateVolumeChange",

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADSP_LIB") or os.path.join(_HERE, "libadsp.so")  # ADSP_LIB: tuning builds only
 
-ADSP_ABI_VERSION = 10
+ADSP_ABI_VERSION = 11
 ADSP_MAX_HISTORY = 8
 ADSP_RCCL_UNIQUE_ID_BYTES = 128
 ADSP_FORMAT_F32, ADSP_FORMAT_S16, ADSP_FORMAT_S16_F64 = 0, 1, 2
@@ -84,6 +84,8 @@ SIGNATURES = {
                                        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "adsp_mix_host": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
                                      ctypes.c_void_p, ctypes.c_size_t]),
+    "adsp_nonfinite_guard": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                            ctypes.c_int, ctypes.c_void_p]),
     "adsp_get_epilogue_state": (ctypes.c_int, [_engine_p, ctypes.POINTER(ctypes.c_longlong)]),
     "adsp_set_epilogue_state": (ctypes.c_int, [_engine_p, ctypes.c_longlong]),
     "adsp_set_accumulate": (ctypes.c_int, [_engine_p, ctypes.c_int]),
@@ -118,6 +120,10 @@ SIGNATURES = {
     "adsp_upols_info": (ctypes.c_int, [ctypes.c_void_p, _c_int_p, _c_int_p, ctypes.POINTER(ctypes.c_size_t)]),
     "adsp_upols_apply_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "adsp_upols_apply_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    "adsp_upols_synchronize": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "adsp_upols_state_bytes": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]),
+    "adsp_upols_get_state": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "adsp_upols_set_state": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "adsp_reset": (ctypes.c_int, [_engine_p]),
     "adsp_apply_host": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "adsp_apply_device": (ctypes.c_int, [_engine_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),

@@ -22,7 +22,7 @@
 //   upols_mac_kernel     : acc += pair_op_p(Z_{b-p}) for p = 0 .. P-1 - the matrix of a pair formed in the kernel from 16 bytes of
 //                          table per pair and partition ((2s, 2d) of H_p's two bins) and the bin's twiddle - then the inverse passes,
 //                          the kept half [B, 2B) converted / passed through a fused effect and stored.  The launch is bound by what
-//                          the L2 delivers (tables + spectra: 24 P bytes per output sample, 88 % hits), not by issue or HBM.
+//                          the L1 / L2 path delivers (tables + spectra: 16 P bytes per output sample - 8 of table, 8 of spectrum).
 // The second launch reads what the first one wrote: the kernel boundary is the only synchronisation (no flags, no scopes).
 // Consecutive blocks of a channel share P - 1 spectra; blockIdx -> (channel, block) keeps them on one XCD (their L2).
 //
@@ -74,6 +74,11 @@ struct UpolsArgs {
     int pair_stride, pair0_stride;
     int epi_op;
     float epi_p0, epi_p1, epi_p2;
+    // the multiply launch's extra workgroups (blockIdx >= mac_grid, one per channel) keep the input's tail for the next call's windows
+    void* ring_w;        // = ring
+    int mac_grid;        // workgroups of the multiply-accumulate proper
+    int tail;            // samples per channel to keep: min(2B, n_steps N) - no later window reaches further back (multiple of 4)
+    int cnt;             // chunks of this call that enter the ring: min(n_steps, nh)
 };
 
 namespace {
@@ -213,6 +218,29 @@ __global__ __launch_bounds__(PL::T, PL::P > 32 ? 2 : 3) void upols_forward_kerne
     }
 }
 
+// The ring keeps what later calls' windows can still reach of this call's input: a window starts less than two blocks before the first
+// sample of the call that completes it, so only the LAST 2B samples of a call's input are ever read again - 16384 of Example4's 88200
+// per channel.  One workgroup per channel at the end of the multiply launch's grid (which reads neither the input nor the ring)
+// copies them, 16 (int16: 8) bytes per lane; rounds 1 - 5 copied whole chunks with hipMemcpyAsync behind the kernels (9 us of a 65 us
+// call at 64 channels, 145 of 955 at 1024).
+template <bool S16>
+__device__ __forceinline__ void upols_keep_tail(const UpolsArgs& a) {
+    using V = typename std::conditional<S16, uint2, uint4>::type;  // four samples
+    const int c = static_cast<int>(blockIdx.x) - a.mac_grid;
+    if (c >= a.C) return;
+    const int N = a.N, first = a.n_steps * N - a.tail;
+    const size_t plane = static_cast<size_t>(a.C) * N / 4, chan = static_cast<size_t>(c) * N / 4;
+    const V* in = static_cast<const V*>(a.in);
+    V* ring = static_cast<V*>(a.ring_w);
+    for (int u = static_cast<int>(threadIdx.x); u < a.tail / 4; u += static_cast<int>(blockDim.x)) {
+        int k, r;
+        locate_chunk(first + 4 * u, N, a.inv_n, k, r);
+        int slot = a.ring_pos + 1 + (k - (a.n_steps - a.cnt));
+        slot -= slot >= a.ring_slots ? a.ring_slots : 0;
+        ring[static_cast<size_t>(slot) * plane + chan + r / 4] = in[static_cast<size_t>(k) * plane + chan + r / 4];
+    }
+}
+
 // ---- launch 2: sum over partitions of pair_op_p(Z_{b-p}) -> inverse passes -> kept half ----------------------------------
 template <class PL, bool S16>
 __global__ __launch_bounds__(PL::T, ADSP_UPOLS_MAC_WAVES) void upols_mac_kernel(const UpolsArgs a) {
@@ -220,6 +248,10 @@ __global__ __launch_bounds__(PL::T, ADSP_UPOLS_MAC_WAVES) void upols_mac_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     real2* lds = reinterpret_cast<real2*>(smem_raw);
     const int tid = static_cast<int>(threadIdx.x);
+    if (static_cast<int>(blockIdx.x) >= a.mac_grid) {  // workgroup-uniform
+        upols_keep_tail<S16>(a);
+        return;
+    }
     int c, blk;
     if (!upols_block<PL>(a, c, blk)) return;
 
@@ -318,8 +350,14 @@ __global__ __launch_bounds__(PL::T, ADSP_UPOLS_MAC_WAVES) void upols_mac_kernel(
         pair_of(2 * h + 1, s.t1, s.za.z, s.za.w, s.zb.z, s.zb.w);
     };
     {
-        const float2* z = block_of(0);
-        const float4* tab = a.pair;
+        // Partition order: block b starts with partition b mod P and wraps around, so that the workgroups of a channel's consecutive
+        // blocks - which start together and advance in step - want the SAME block Z_{b-p} of the delay line at the same time: one
+        // fetch from HBM serves them all out of the L2.  (In the order 0 .. P-1 they read P different blocks per step and met each
+        // again a step later, by when the XCD's other workgroups had pushed 4 - 8 MB through its 4 MB L2: the launch fetched
+        // every block about twice, profiles/r5_upols_1024ch_counters.txt.)
+        int p = (a.slot_first + blk) % a.P;
+        const float2* z = block_of(p);
+        const float4* tab = a.pair + static_cast<size_t>(p) * a.pair_stride;
 #pragma unroll
         for (int h = 0; h < kAhead; ++h) request(st[h], z, tab, h);
         auto partition = [&](auto more, const float2* zn, const float4* tabn) {  // straight-line code: no branch inside a partition
@@ -331,9 +369,10 @@ __global__ __launch_bounds__(PL::T, ADSP_UPOLS_MAC_WAVES) void upols_mac_kernel(
                 __builtin_amdgcn_sched_barrier(0);  // keep the requests where they are: kAhead stages of registers, not a partition's
             }
         };
-        for (int p = 1; p < a.P; ++p) {
+        for (int s = 1; s < a.P; ++s) {
+            p = p + 1 == a.P ? 0 : p + 1;
             const float2* zn = block_of(p);
-            const float4* tabn = tab + a.pair_stride;
+            const float4* tabn = a.pair + static_cast<size_t>(p) * a.pair_stride;
             partition(std::true_type{}, zn, tabn);
             z = zn;
             tab = tabn;
@@ -410,7 +449,7 @@ using namespace adsp;
 using namespace adsp::tables;
 // The block sizes of this build: B = 8192 on the 32-points-per-thread plan (32 KiB of LDS, three / two workgroups per CU) and
 // B = 16384 on the 64-points-per-thread plan (64 KiB, two workgroups per CU).  Per output sample the multiply launch reads
-// n_partitions x 20 bytes, and n_partitions = ceil(taps / B): the larger block halves what bounds the engine, for ~8 % more transform work.
+// n_partitions x 16 bytes (8 of table, 8 of spectrum), and n_partitions = ceil(taps / B): the larger block halves what bounds the engine, for ~8 % more transform work.
 struct UpolsPlan {
     int block, threads, lds_bytes;
     PlanInfo shape;
@@ -458,6 +497,9 @@ struct adsp_upols {
     bool prepared;
     char *stage_in, *stage_out;
     size_t stage_bytes;
+    hipEvent_t ev_done;        // recorded behind every launch pair: a call on ANOTHER stream waits for it (the delay line and the ring are shared state)
+    hipStream_t last_stream;
+    bool launched;
     size_t ssize() const { return cfg.sample_format == ADSP_FORMAT_F32 ? sizeof(float) : sizeof(short); }
     size_t plane_bytes() const { return (size_t)cfg.n_channels * cfg.chunk_size * ssize(); }
     size_t zline_bytes() const { return (size_t)cfg.n_channels * R * plan->block * sizeof(float2); }
@@ -522,15 +564,14 @@ int upols_launch_pair(adsp_upols* u, const void* d_in, void* d_out, int n, hipSt
     a.slot_first = (int)(((b_lo % u->R) + u->R) % u->R);
     a.rel_first = (int)(b_lo * kB + c.delay - t_call);  // output time of the block's first kept sample (circular index B)
     const long long grid = groups * a.nblk;
-    if (grid > 0x7fffffffLL) return fail(ADSP_ERR_ARG, "launch too large (%lld workgroups)", grid);
-    HIP_TRY(hipLaunchKernel(pl.mac[s16 ? 1 : 0], dim3((unsigned)grid), dim3(pl.threads), kargs, pl.lds_bytes, stream));
-    // 3. the ring keeps the last nh chunks (read by the next call's forward launch): stream-ordered copies behind the kernels
-    const size_t plane = u->plane_bytes();
+    // ... plus one workgroup per channel that keeps the input's tail (the last min(2B, n N) samples) in the ring for the next call's windows
     const int cnt = n < u->nh ? n : u->nh;
-    for (int i = 0; i < cnt; ++i) {
-        const int slot = (u->ring_pos + 1 + i) % u->ring_slots;
-        HIP_TRY(hipMemcpyAsync(u->ring + (size_t)slot * plane, static_cast<const char*>(d_in) + (size_t)(n - cnt + i) * plane, plane, hipMemcpyDefault, stream));
-    }
+    a.ring_w = u->ring;
+    a.mac_grid = (int)grid;
+    a.tail = (int)((long long)n * N < 2 * kB ? (long long)n * N : 2 * kB);
+    a.cnt = cnt;
+    if (grid + c.n_channels > 0x7fffffffLL) return fail(ADSP_ERR_ARG, "launch too large (%lld workgroups)", grid + c.n_channels);
+    HIP_TRY(hipLaunchKernel(pl.mac[s16 ? 1 : 0], dim3((unsigned)(grid + c.n_channels)), dim3(pl.threads), kargs, pl.lds_bytes, stream));
     u->ring_pos = (u->ring_pos + cnt) % u->ring_slots;
     u->steps_done += n;
     return ADSP_OK;
@@ -592,6 +633,7 @@ int adsp_upols_create(const adsp_upols_config* cfg, const float* spectra, adsp_u
     };
     hipError_t err;
     if ((err = hipSetDevice(cfg->device_id)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(err)));
+    if ((err = hipEventCreateWithFlags(&u->ev_done, hipEventDisableTiming)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(err)));
     for (const void* fn : {plan->fwd[0], plan->fwd[1], plan->mac[0], plan->mac[1]})
         if ((err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, plan->lds_bytes)) != hipSuccess)
             return bail(fail(ADSP_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(err)));
@@ -652,6 +694,7 @@ void adsp_upols_destroy(adsp_upols* u) {
     (void)hipDeviceSynchronize();
     for (void* p : {(void*)u->ring, (void*)u->zeros, (void*)u->tw, (void*)u->pair, (void*)u->pair0, (void*)u->zline, (void*)u->stage_in, (void*)u->stage_out})
         if (p) (void)hipFree(p);
+    if (u->ev_done) (void)hipEventDestroy(u->ev_done);
     delete u;
 }
 
@@ -697,13 +740,95 @@ int adsp_upols_apply_device(adsp_upols* u, const void* d_in, void* d_out, int n_
         const size_t span = (size_t)n_steps * plane;
         if (i0 < o0 + span && o0 < i0 + span) return fail(ADSP_ERR_ARG, "d_in and d_out overlap: the partitioned engines do not run in place");
     }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (u->launched && st != u->last_stream) HIP_TRY(hipStreamWaitEvent(st, u->ev_done, 0));  // the previous call ran on another stream
     for (int done = 0; done < n_steps;) {  // at most max_steps chunks per launch pair (the delay line is sized for that)
         const int n = n_steps - done < u->cfg.max_steps ? n_steps - done : u->cfg.max_steps;
-        const int rc = upols_launch_pair(u, static_cast<const char*>(d_in) + (size_t)done * plane, static_cast<char*>(d_out) + (size_t)done * plane, n,
-                                         static_cast<hipStream_t>(stream));
+        const int rc = upols_launch_pair(u, static_cast<const char*>(d_in) + (size_t)done * plane, static_cast<char*>(d_out) + (size_t)done * plane, n, st);
         if (rc) return rc;
         done += n;
     }
+    HIP_TRY(hipEventRecord(u->ev_done, st));
+    u->last_stream = st;
+    u->launched = true;
+    return ADSP_OK;
+}
+
+int adsp_upols_synchronize(adsp_upols* u, void* stream) {
+    if (!u) return fail(ADSP_ERR_ARG, "NULL engine");
+    HIP_TRY(hipSetDevice(u->cfg.device_id));
+    if (u->launched && static_cast<hipStream_t>(stream) != u->last_stream) HIP_TRY(hipEventSynchronize(u->ev_done));
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return ADSP_OK;
+}
+
+// A checkpoint is the engine's whole device state: counters, the input ring (tails) and the frequency-domain delay line.
+namespace {
+struct UpolsStateHeader {
+    unsigned magic, version;
+    adsp_upols_config cfg;
+    int ring_slots, R, ring_pos, reserved;
+    long long steps_done, fwd_done;
+    unsigned long long ring_bytes, zline_bytes;
+};
+constexpr unsigned kStateMagic = 0x55504f4cu;  // "UPOL"
+}  // namespace
+
+int adsp_upols_state_bytes(const adsp_upols* u, size_t* bytes) {
+    if (!u || !bytes) return fail(ADSP_ERR_ARG, "NULL argument");
+    *bytes = sizeof(UpolsStateHeader) + (size_t)u->ring_slots * u->plane_bytes() + u->zline_bytes();
+    return ADSP_OK;
+}
+
+int adsp_upols_get_state(adsp_upols* u, void* state, size_t capacity) {
+    if (!u || !state) return fail(ADSP_ERR_ARG, "NULL argument");
+    size_t need = 0;
+    adsp_upols_state_bytes(u, &need);
+    if (capacity < need) return fail(ADSP_ERR_ARG, "state buffer of %zu bytes, the engine's state takes %zu (adsp_upols_state_bytes)", capacity, need);
+    HIP_TRY(hipSetDevice(u->cfg.device_id));
+    HIP_TRY(hipDeviceSynchronize());
+    UpolsStateHeader h;
+    memset(&h, 0, sizeof h);
+    h.magic = kStateMagic;
+    h.version = ADSP_ABI_VERSION;
+    h.cfg = u->cfg;
+    h.ring_slots = u->ring_slots;
+    h.R = u->R;
+    h.ring_pos = u->ring_pos;
+    h.steps_done = u->steps_done;
+    h.fwd_done = u->fwd_done;
+    h.ring_bytes = (size_t)u->ring_slots * u->plane_bytes();
+    h.zline_bytes = u->zline_bytes();
+    char* out = static_cast<char*>(state);
+    memcpy(out, &h, sizeof h);
+    HIP_TRY(hipMemcpy(out + sizeof h, u->ring, h.ring_bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out + sizeof h + h.ring_bytes, u->zline, h.zline_bytes, hipMemcpyDeviceToHost));
+    return ADSP_OK;
+}
+
+int adsp_upols_set_state(adsp_upols* u, const void* state, size_t bytes) {
+    if (!u || !state) return fail(ADSP_ERR_ARG, "NULL argument");
+    UpolsStateHeader h;
+    if (bytes < sizeof h) return fail(ADSP_ERR_ARG, "state of %zu bytes is shorter than its header", bytes);
+    memcpy(&h, state, sizeof h);
+    if (h.magic != kStateMagic) return fail(ADSP_ERR_ARG, "not a state of a partitioned engine (magic %08x)", h.magic);
+    const adsp_upols_config& c = u->cfg;
+    if (h.cfg.chunk_size != c.chunk_size || h.cfg.n_channels != c.n_channels || h.cfg.block_size != c.block_size ||
+        h.cfg.n_partitions != c.n_partitions || h.cfg.delay != c.delay || h.cfg.sample_format != c.sample_format || h.cfg.max_steps != c.max_steps ||
+        h.ring_slots != u->ring_slots || h.R != u->R)
+        return fail(ADSP_ERR_ARG, "the state was taken from an engine of another shape (chunk %d, %d channels, block %d, %d partitions, delay %d, format %d, max_steps %d)",
+                    h.cfg.chunk_size, h.cfg.n_channels, h.cfg.block_size, h.cfg.n_partitions, h.cfg.delay, h.cfg.sample_format, h.cfg.max_steps);
+    if (h.ring_bytes != (size_t)u->ring_slots * u->plane_bytes() || h.zline_bytes != u->zline_bytes() || bytes < sizeof h + h.ring_bytes + h.zline_bytes)
+        return fail(ADSP_ERR_ARG, "truncated state (%zu bytes)", bytes);
+    if (h.ring_pos < 0 || h.ring_pos >= u->ring_slots || h.steps_done < 0 || h.fwd_done < -1) return fail(ADSP_ERR_ARG, "corrupt state header");
+    HIP_TRY(hipSetDevice(c.device_id));
+    HIP_TRY(hipDeviceSynchronize());
+    const char* in = static_cast<const char*>(state);
+    HIP_TRY(hipMemcpy(u->ring, in + sizeof h, h.ring_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(u->zline, in + sizeof h + h.ring_bytes, h.zline_bytes, hipMemcpyHostToDevice));
+    u->ring_pos = h.ring_pos;
+    u->steps_done = h.steps_done;
+    u->fwd_done = h.fwd_done;
     return ADSP_OK;
 }
 

@@ -547,8 +547,21 @@ class UpolsFirEngine:
         return out[0] if squeeze else out
 
     def synchronize(self, stream=None):
-        import torch  # plumbing only (the engine has no synchronise entry point of its own)
-        torch.cuda.synchronize(self.device)
+        """Wait for everything the engine has launched (on `stream`, or wherever its last call went)."""
+        _capi.check(self._lib.adsp_upols_synchronize(self._h, _ptr(stream)))
+
+    def get_state(self):
+        """The engine's whole state as one uint8 array (counters, input ring, frequency-domain delay line: adsp_upols_get_state);
+        set_state on an engine of the same configuration continues the stream bit for bit."""
+        n = ctypes.c_size_t(0)
+        _capi.check(self._lib.adsp_upols_state_bytes(self._h, ctypes.byref(n)))
+        out = np.empty(n.value, np.uint8)
+        _capi.check(self._lib.adsp_upols_get_state(self._h, _ptr(out), out.size))
+        return out
+
+    def set_state(self, state):
+        st = np.ascontiguousarray(state, dtype=np.uint8)
+        _capi.check(self._lib.adsp_upols_set_state(self._h, _ptr(st), st.size))
 
 
 class MixBus:

@@ -1,0 +1,290 @@
+"""Round 6: reference CALL PATTERNS that had no fixture - Example4's in-place loop (history aliased by the caller's
+array), Example3's callback thread, non-finite samples - and the round's engine work.  Run with -m gpu on MI355X."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_parity, load_golden, seeded_stream  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+SEEDS = {"LC": 201, "HC": 202, "EQ": 203}
+
+
+@pytest.fixture(scope="module")
+def adsp():
+    import pyaudiodsptools_amd as pkg
+    from pyaudiodsptools_amd import _capi
+    assert _capi.device_count() >= 1, "no GPU visible: the HIP path cannot run (no CPU fallback by design)"
+    return pkg
+
+
+def orc():
+    from oracle import fftfilter_oracle as o
+    return o
+
+
+def _make(adsp, tag, **kw):
+    return {"LC": lambda: adsp.CreateLowCutFilterGPU(300, **kw), "HC": lambda: adsp.CreateHighCutFilterGPU(8000, **kw),
+            "EQ": lambda: adsp.CreateEQ3BandFFTGPU(100, 2, 700, -4, 8000, 5, **kw)}[tag]()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 1. Example4's loop: split_data = array(MakeChunks(x)); split_data[i] = device.apply(split_data[i])   (Example4.py:9,18-19)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["LC", "HC", "EQ"])
+@pytest.mark.parametrize("n,chunks,dec", [(512, 8, 1), (88200, 4, 64)])
+@pytest.mark.parametrize("carrier", ["numpy", "torch"])
+def test_example4_in_place_loop(adsp, tag, n, chunks, dec, carrier):
+    """The reference's devices keep views of the rows as history, so its result is a filter over its own previous OUTPUTS
+    (kat_inplace.npz, from the real reference).  Default here: the caller's array is copied, the loop returns the clean FIR stream -
+    asserted against the reference's clean stream, with the measured distance to the reference's in-place result on record;
+    alias_history=True: the reference's in-place result."""
+    import torch
+    kat = load_golden("kat_inplace")
+    want_inplace, want_clean = kat[f"{tag}{n}_inplace"], kat[f"{tag}{n}_clean"]
+    adsp.config.initialize(44100, n)
+    x = seeded_stream(SEEDS[tag] + n, chunks * n)
+
+    def loop(dev):
+        if carrier == "numpy":
+            arr = np.array(orc().make_chunks(x.copy(), n))
+            for i in range(len(arr)):
+                arr[i] = dev.apply(arr[i])
+            return arr.reshape(-1)[::dec]
+        arr = torch.from_numpy(x.copy()).cuda().reshape(chunks, n)   # cupy.array(MakeChunks(...)) in the reference
+        for i in range(len(arr)):
+            arr[i] = dev.apply(arr[i])
+        return arr.cpu().numpy().reshape(-1)[::dec]
+
+    try:
+        clean = loop(_make(adsp, tag))
+        assert_parity(clean, want_clean, what=f"{tag}{n} default (history copied): the FIR stream")
+        apart = np.abs(clean - want_inplace).max() / np.abs(want_clean).max()
+        assert apart > 0.5, "the documented divergence: the reference's in-place loop is full-scale away from the FIR stream"
+        aliased = loop(_make(adsp, tag, alias_history=True))
+        # The loop is a FEEDBACK system (every call re-filters the previous calls' outputs), so a rounding difference of one call is
+        # filtered again by each later one: the whole loop is held to north_star's bound, max|d| <= 1e-5 max|ref| ...
+        assert np.abs(aliased - want_inplace).max() <= 1e-5 * np.abs(want_inplace).max(), f"{tag}{n} alias_history=True: the in-place loop"
+        # ... and every single call, given the reference's own (out[k-2], out[k-1], x[k]), to the suite's full criterion
+        if dec == 1:
+            ref_rows, xs = want_inplace.reshape(chunks, n), x.reshape(chunks, n)
+            zero = np.zeros(n, np.float32)
+            for k in range(chunks):
+                dev = _make(adsp, tag, alias_history=True)
+                dev.apply(ref_rows[k - 2].copy() if k >= 2 else zero)
+                dev.apply(ref_rows[k - 1].copy() if k >= 1 else zero)
+                assert_parity(dev.apply(xs[k]), ref_rows[k], what=f"{tag}{n} call {k} on the reference's own history")
+    finally:
+        adsp.config.initialize(44100, 4096)
+
+
+def test_alias_history_follows_any_later_write_to_a_passed_chunk(adsp):
+    """Not only Example4's pattern: whatever the caller writes into an array it has passed is what the next two calls transform
+    (EffectFFTFilter.py:63-68) - checked against the oracle, which keeps references like the reference does."""
+    n = 512
+    adsp.config.initialize(44100, n)
+    rng = np.random.default_rng(5)
+    dev, ref = adsp.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5, alias_history=True), orc().OracleEQ3BandFFT(100, 2, 700, -4, 8000, 5, 44100, n)
+    bufs = [rng.uniform(-1, 1, n).astype(np.float32) for _ in range(6)]
+    twin = [b.copy() for b in bufs]
+    for k in range(6):
+        got, want = dev.apply(bufs[k]), ref.apply(twin[k])
+        assert_parity(got, want, what=f"call {k}")
+        bufs[k] *= np.float32(0.5)      # scale the chunk just passed ...
+        twin[k] *= np.float32(0.5)
+        if k >= 1:
+            bufs[k - 1][::7] = 0.25     # ... and poke into the one before
+            twin[k - 1][::7] = 0.25
+    with pytest.raises(ValueError):
+        adsp.CreateLowCutFilter(300, channels=4, alias_history=True)
+    adsp.config.initialize(44100, 4096)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 2. Non-finite samples
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["LC", "HC", "EQ"])
+@pytest.mark.parametrize("vname,value", [("nan", np.nan), ("pinf", np.inf), ("ninf", -np.inf)])
+@pytest.mark.parametrize("carrier", ["numpy", "torch", "mixed"])
+def test_apply_poisons_the_calls_the_reference_poisons(adsp, tag, vname, value, carrier):
+    """One NaN / Inf sample: the reference returns all-NaN chunks from the call that takes it and the two after it, and clean chunks
+    again from the third (kat_nonfinite.npz).  apply() does the same for host chunks, device-resident chunks and a mixture."""
+    import torch
+    nf = load_golden("kat_nonfinite")
+    n, chunks, where = 512, 8, int(nf["position"][0])
+    adsp.config.initialize(44100, n)
+    x = seeded_stream(SEEDS[tag] + 7, chunks * n)
+    x[where] = value
+    dev = _make(adsp, tag)
+    outs = []
+    for k in range(chunks):
+        chunk = x[k * n:(k + 1) * n]
+        on_gpu = carrier == "torch" or (carrier == "mixed" and k in (2, 4, 5))
+        y = dev.apply(torch.from_numpy(chunk).cuda() if on_gpu else chunk)
+        outs.append(y.cpu().numpy() if on_gpu else y)
+    out = np.stack(outs)
+    assert np.array_equal((~np.isfinite(out)).sum(axis=1), nf[f"{tag}_{vname}_nonfinite_per_call"])
+    assert np.array_equal(np.isnan(out).sum(axis=1), nf[f"{tag}_{vname}_nan_per_call"])
+    assert_parity(out[np.isfinite(out).all(axis=1)].reshape(-1), nf[f"{tag}_{vname}_finite_calls"], what="the finite calls")
+    adsp.config.initialize(44100, 4096)
+
+
+@pytest.mark.parametrize("n,channels", [(512, 5), (4096, 3), (88200, 2)])
+def test_batches_poison_between_the_fir_support_and_the_references_three_chunks(adsp, n, channels):
+    """apply_batch (not a reference entry point) lets the kernels' arithmetic decide: the non-finite outputs are a SUPERSET of the
+    samples the FIR's support reaches from the bad sample and a SUBSET of the reference's three chunks; other channels stay clean."""
+    adsp.config.initialize(44100, n)
+    chunks = 7
+    x = seeded_stream(n + channels, chunks * channels * n).reshape(chunks, channels, n).copy()
+    pos = 2 * n + (3 * n) // 5          # absolute sample index of the bad sample in channel 1
+    x[pos // n, 1, pos % n] = np.nan
+    dev = adsp.CreateLowCutFilter(300, channels=channels)
+    with np.errstate(all="ignore"):
+        y = np.stack([dev.apply_batch(x[k]) for k in range(chunks)])
+    bad = ~np.isfinite(y)
+    assert not bad[:, [c for c in range(channels) if c != 1]].any(), "channels are independent"
+    bad1 = bad[:, 1].reshape(-1)
+    taps, d = dev.filter_length, dev.filter_length // 2
+    # out[tau] = sum_t c[t] s[tau - N + d - t]: the sample at `pos` reaches tau in [pos + N - d, pos + N - d + taps)
+    lo, hi = pos + n - d, pos + n - d + taps
+    assert bad1[lo:hi].all(), "every output the FIR's support reaches is non-finite"
+    k = pos // n
+    assert not bad1[:k * n].any() and not bad1[(k + 3) * n:].any(), "nothing outside the reference's three chunks"
+    adsp.config.initialize(44100, 4096)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 3. Example3's call pattern: apply() from a thread that did not create the device (PortAudio's callback thread, Example3.py:20-24)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_apply_from_a_thread_that_did_not_create_the_device(adsp):
+    n = 512
+    adsp.config.initialize(44100, n)
+    dev = adsp.CreateLowCutFilter(200)                       # created on the main thread (Example3.py:13)
+    kat = load_golden("kat_streams")["D"]                    # LowCut(200), seed 1234, 6 chunks, from the reference
+    x = seeded_stream(1234, 6 * n)
+    long_x = seeded_stream(4242, 200 * n)
+    ref = orc().OracleLowCut(200, 44100, n)
+    want_long = np.concatenate([ref.apply(long_x[i * n:(i + 1) * n]) for i in range(200)])
+    result = {}
+
+    def callback_thread():
+        try:
+            result["D"] = np.concatenate([dev.apply(x[i * n:(i + 1) * n]) for i in range(6)])
+            dev.reset()
+            result["long"] = np.concatenate([dev.apply(np.frombuffer(long_x[i * n:(i + 1) * n].tobytes(), dtype=np.float32)) for i in range(200)])
+        except BaseException as exc:  # noqa: BLE001 - reported on the main thread
+            result["error"] = exc
+
+    t = threading.Thread(target=callback_thread)
+    t.start()
+    t.join(120)
+    assert not t.is_alive() and "error" not in result, result.get("error")
+    assert_parity(result["D"], kat, what="golden D from a second thread")
+    assert_parity(result["long"], want_long, what="200 calls from a second thread")
+    # ... and the main thread continues the same stream afterwards (state lives in the engine, not in the thread)
+    more = seeded_stream(4243, 2 * n)
+    got = np.concatenate([dev.apply(more[:n]), dev.apply(more[n:])])
+    want = np.concatenate([ref.apply(more[:n]), ref.apply(more[n:])])
+    assert_parity(got, want, what="main thread continues")
+    adsp.config.initialize(44100, 4096)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 4. The long-kernel engine's surface: checkpoint / resume, synchronise, calls on changing streams, the tail-only ring
+# ---------------------------------------------------------------------------------------------------------------------
+def _long_fir(adsp, n=88200, taps_len=44099, seed=3, latency=1):
+    rng = np.random.default_rng(seed)
+    taps = rng.standard_normal(taps_len) * np.hanning(taps_len) / np.sqrt(taps_len) * 3.0
+    return adsp.FirStream(taps, n, latency_chunks=latency, lookahead=taps_len // 2), taps
+
+
+@pytest.mark.parametrize("block", [8192, 16384])
+def test_upols_state_roundtrip_reset_and_refusals(adsp, block):
+    """Mirrors test_multistep_equals_streaming_and_state_roundtrip for the partitioned engine: a checkpoint taken mid-stream and
+    restored into a FRESH engine continues the stream bit for bit; reset returns to the zero state; a state of another shape is refused."""
+    fir, _ = _long_fir(adsp)
+    n, channels, steps = fir.chunk_size, 3, 6
+    x = seeded_stream(77, steps * channels * n).reshape(steps, channels, n)
+    a = adsp.UpolsFirEngine(fir, channels=channels, block=block)
+    whole = np.concatenate([a.apply_host(x[k:k + 1]) for k in range(steps)])
+    b = adsp.UpolsFirEngine(fir, channels=channels, block=block)
+    part1 = np.concatenate([b.apply_host(x[k:k + 1]) for k in range(3)])
+    state = b.get_state()
+    assert state.dtype == np.uint8 and state.size > b.delay_line_bytes
+    part2 = np.concatenate([b.apply_host(x[k:k + 1]) for k in range(3, steps)])
+    assert np.array_equal(np.concatenate([part1, part2]), whole)
+    c = adsp.UpolsFirEngine(fir, channels=channels, block=block)
+    c.set_state(state)
+    assert np.array_equal(np.concatenate([c.apply_host(x[k:k + 1]) for k in range(3, steps)]), part2), "resume is bit for bit"
+    c.reset()
+    assert np.array_equal(np.concatenate([c.apply_host(x[k:k + 1]) for k in range(3)]), part1), "after reset"
+    other = adsp.UpolsFirEngine(fir, channels=channels + 1, block=block)
+    with pytest.raises(adsp.AdspError):
+        other.set_state(state)
+    with pytest.raises(adsp.AdspError):
+        c.set_state(state[:1000])
+    bad = state.copy()
+    bad[0] ^= 0xFF
+    with pytest.raises(adsp.AdspError):
+        c.set_state(bad)
+    for e in (a, b, c, other):
+        e.close()
+
+
+def test_upols_calls_on_changing_streams_and_synchronize(adsp):
+    """numpy chunks (NULL stream) and device tensors under non-default, non-blocking torch streams alternate on one
+    long-kernel device; the library orders the calls itself (event behind every launch pair) and synchronize(stream) waits for the
+    engine's last call wherever it went."""
+    import torch
+    fir, taps = _long_fir(adsp, n=20000, taps_len=30001, seed=9, latency=2)
+    n, channels, steps = fir.chunk_size, 2, 8
+    x = seeded_stream(78, steps * channels * n).reshape(steps, channels, n)
+    ref = adsp.UpolsFirEngine(fir, channels=channels)
+    want = np.concatenate([ref.apply_host(x[k:k + 1]) for k in range(steps)])
+    eng = adsp.UpolsFirEngine(fir, channels=channels)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    xd = torch.from_numpy(x).cuda()
+    outs = [None] * steps
+    torch.cuda.synchronize()
+    for k in range(steps):
+        if k % 3 == 0:
+            outs[k] = torch.from_numpy(eng.apply_host(x[k:k + 1])).cuda()
+        else:
+            s = streams[k % 2]
+            outs[k] = torch.empty((1, channels, n), device="cuda")
+            eng.apply_device(xd[k:k + 1], outs[k], 1, s.cuda_stream)
+    eng.synchronize(streams[0].cuda_stream)   # the last call (k = 7) went to streams[1]: still waited for
+    got = torch.cat(outs).cpu().numpy()
+    assert np.array_equal(got, want)
+    for c in range(channels):
+        truth = orc().direct_stream_convolution(taps, x[:, c].reshape(-1), n, fir.latency_chunks, fir.lookahead)
+        assert_parity(got[:, c].reshape(-1), truth, what=f"channel {c}")
+    ref.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("n,taps_len,latency,calls", [(88200, 44099, 1, [1, 1, 1, 1]), (3000, 20001, 9, [1, 7, 2, 30, 1, 1]),
+                                                      (16, 9001, 1306, [600, 1, 1500, 3])])
+def test_upols_ring_keeps_only_the_tail_that_later_windows_reach(adsp, n, taps_len, latency, calls):
+    """The ring update copies the last 2B samples of a call's input (one workgroup per channel inside the multiply launch) instead of
+    whole chunks: chunk sizes above, near and far below the block size, calls of many chunks, against the float64 direct sum."""
+    import torch
+    fir, taps = _long_fir(adsp, n=n, taps_len=taps_len, seed=n, latency=latency)
+    channels, total = 5, sum(calls)
+    x = seeded_stream(79 + n, total * channels * n).reshape(total, channels, n)
+    for block in (8192, 16384):
+        if fir.delay < block:
+            continue
+        eng = adsp.UpolsFirEngine(fir, channels=channels, block=block, max_steps=max(1, min(64, max(calls))))
+        got, k = [], 0
+        for m in calls:
+            got.append(eng.apply_host(x[k:k + m]))
+            k += m
+        got = np.concatenate(got)
+        for c in (0, channels - 1):
+            truth = orc().direct_stream_convolution(taps, x[:, c].reshape(-1), n, latency, fir.lookahead)
+            assert_parity(got[:, c].reshape(-1), truth, what=f"N={n} block {block} channel {c}")
+        eng.close()
+    torch.cuda.synchronize()
