@@ -104,6 +104,11 @@ typedef struct adsp_config {
 /* ABI version (ADSP_ABI_VERSION of the built library). */
 ADSP_API int adsp_version(void);
 
+/* "product": libadsp.so, what `make` builds and the package loads.  "tuning": libadsp_tuning.so (`make tuning`, loaded only through
+ * ADSP_LIB=<path>): the same entry points plus the A/B plan variants (ADSP_PLAN_VARIANT), the ablation switches and the persistent-block
+ * kernels of the speed-of-light model - none of which exist in the product library, which refuses ADSP_PLAN_VARIANT with a message. */
+ADSP_API const char* adsp_build_info(void);
+
 /* Thread-local description of the last failure on this thread ("" if none). */
 ADSP_API const char* adsp_last_error(void);
 

@@ -63,6 +63,7 @@ _engine_p = ctypes.c_void_p
 SIGNATURES = {
     "adsp_version": (ctypes.c_int, []),
     "adsp_last_error": (ctypes.c_char_p, []),
+    "adsp_build_info": (ctypes.c_char_p, []),
     "adsp_device_count": (ctypes.c_int, [_c_int_p]),
     "adsp_plan_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "adsp_plan_describe": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _c_int_p, _c_int_p, _c_int_p, _c_int_p, _c_int_p]),

@@ -11,6 +11,8 @@
 #include <cstring>
 #include <ctime>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <utility>
@@ -139,6 +141,7 @@ using namespace adsp::tables;
 
 const PlanInfo* find_plan(int M, int FQ, int fmt) {
     int n = 0;
+#ifdef ADSP_TUNING_BUILD  // the A/B plans of plans_var.hip are linked into libadsp_tuning.so only (make tuning)
     if (fmt == ADSP_FORMAT_F32) {
         const char* v = getenv("ADSP_PLAN_VARIANT");
         if (v && *v) {  // (an EMPTY value is "not set": atoi("") would select variant 0 - it did, in two A/B sessions of round 5)
@@ -147,6 +150,7 @@ const PlanInfo* find_plan(int M, int FQ, int fmt) {
             if (i >= 0 && i < n && var[i].M == M && var[i].FQ == FQ) return &var[i];
         }
     }
+#endif
     const PlanInfo* tab = fmt == ADSP_FORMAT_S16_F64 ? adsp::plans_s16_f64(&n) : fmt == ADSP_FORMAT_S16 ? adsp::plans_s16(&n) : adsp::plans_f32(&n);
     for (int i = 0; i < n; ++i)
         if (tab[i].M == M && tab[i].FQ == FQ) return &tab[i];
@@ -175,6 +179,11 @@ int ilog2(int v) {
 bool unaligned_chunk(int N) { return N % 4 != 0 || N < 16; }
 
 int check_geometry(int N, int F, int fmt, const PlanInfo** out, bool* generic) {
+#ifndef ADSP_TUNING_BUILD
+    if (const char* v = getenv("ADSP_PLAN_VARIANT"))
+        if (*v) return fail(ADSP_ERR_STATE, "ADSP_PLAN_VARIANT=%s is set, but this is the product library: the A/B plan variants (and the ablation / persistent-block "
+                            "kernels) live in libadsp_tuning.so - `make -C pyaudiodsptools_amd/csrc tuning`, then ADSP_LIB=<path>/libadsp_tuning.so", v);
+#endif
     if (fmt != ADSP_FORMAT_F32 && fmt != ADSP_FORMAT_S16 && fmt != ADSP_FORMAT_S16_F64)
         return fail(ADSP_ERR_ARG, "sample_format %d: need ADSP_FORMAT_F32, ADSP_FORMAT_S16 or ADSP_FORMAT_S16_F64", fmt);
     if (N < 4) return fail(ADSP_ERR_ARG, "chunk_size %d: need at least 4 samples", N);
@@ -474,6 +483,7 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
     }
     a.blk_iters = 1;
     a.self = nullptr;
+#ifdef ADSP_TUNING_BUILD
     if (getenv("ADSP_PERSIST_BUILD")) {  // tuning: a library whose kernels were built with -DADSP_PERSIST=1 (they read their arguments from a.self)
         const char* bi = getenv("ADSP_BLK_ITERS");
         a.blk_iters = (bi && !resident && !e->generic && atoi(bi) > 1) ? atoi(bi) : 1;
@@ -483,6 +493,7 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
         if (!slot) HIP_TRY(hipMalloc(&slot, sizeof a));
         a.self = slot;
     }
+#endif
     const long long grid = (long long)((a.ncg + 7) / 8) * 8 *
                            (resident ? (a.nblk + a.step_tile - 1) / a.step_tile * a.step_tile : (a.nblk + a.blk_iters - 1) / a.blk_iters);  // resident: whole step tiles
     if (grid > 0x7fffffffLL) return fail(ADSP_ERR_ARG, "launch too large (%lld workgroups)", grid);
@@ -536,6 +547,14 @@ int live_pipe_check(adsp_engine* e);
 extern "C" {
 
 int adsp_version(void) { return ADSP_ABI_VERSION; }
+
+const char* adsp_build_info(void) {
+#ifdef ADSP_TUNING_BUILD
+    return "tuning";
+#else
+    return "product";
+#endif
+}
 
 const char* adsp_last_error(void) { return g_last_error.c_str(); }
 
@@ -2172,6 +2191,47 @@ void parallel_memcpy(char* dst, const char* src, size_t bytes, int threads) {
     for (auto& th : pool) th.join();
 }
 
+
+// Hand-over between the three host threads of a pipelined host call (copy in, launch, copy out): counters under one mutex, waiters
+// sleep on a condition variable (rounds 4 - 5 spun on atomics with yield(): three cores busy for the length of every large call),
+// and the FIRST failure is kept with the hipError_t of the thread it happened on (hipGetLastError is thread-local: the caller's
+// would say "no error").
+struct PipeSync {
+    std::mutex m;
+    std::condition_variable cv;
+    int staged = 0, issued = 0, drained = 0;
+    bool failed = false;
+    hipError_t err = hipSuccess;
+    const char* where = "";
+    void advance(int& counter, int value) {
+        {
+            std::lock_guard<std::mutex> l(m);
+            counter = value;
+        }
+        cv.notify_all();
+    }
+    bool wait_for(const int& counter, int at_least) {  // false: somebody failed
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return counter >= at_least || failed; });
+        return !failed;
+    }
+    void fail(hipError_t e, const char* what) {
+        {
+            std::lock_guard<std::mutex> l(m);
+            if (!failed) {
+                failed = true;
+                err = e;
+                where = what;
+            }
+        }
+        cv.notify_all();
+    }
+    bool has_failed() {
+        std::lock_guard<std::mutex> l(m);
+        return failed;
+    }
+};
+
 // The slab pipeline in its default form, without pinned staging of the library's own: a copy-in thread and a copy-out thread give the
 // caller's pageable memory to hipMemcpyAsync slab by slab on their own streams; this thread launches the kernels.
 int apply_host_direct_slabs(adsp_engine* e, const char* in, char* out, int n_steps, int slab_steps, int n_slabs) {
@@ -2179,51 +2239,56 @@ int apply_host_direct_slabs(adsp_engine* e, const char* in, char* out, int n_ste
     const size_t step_bytes = e->plane_bytes(), slab_bytes = (size_t)slab_steps * step_bytes;
     const int dev = e->cfg.device_id;
     auto steps_of = [&](int i) { return i + 1 < n_slabs ? slab_steps : n_steps - i * slab_steps; };
-    std::atomic<int> staged{0}, issued{0}, drained{0}, failed{0};
+    PipeSync ps;
     std::thread stager([&] {
-        (void)hipSetDevice(dev);
-        for (int i = 0; i < n_slabs && !failed.load(); ++i) {
+        hipError_t err;
+        if ((err = hipSetDevice(dev)) != hipSuccess) return ps.fail(err, "copy-in thread: hipSetDevice");
+        for (int i = 0; i < n_slabs; ++i) {
             const int b = i & 1;
             if (i >= 2) {  // d_in[b] was read by the kernel (and the ring update) of slab i - 2
-                while (issued.load() < i - 1 && !failed.load()) std::this_thread::yield();
-                if (failed.load()) return;
-                if (hipEventSynchronize(hp.ev_k[b]) != hipSuccess) { failed.store(1); return; }
+                if (!ps.wait_for(ps.issued, i - 1)) return;
+                if ((err = hipEventSynchronize(hp.ev_k[b])) != hipSuccess) return ps.fail(err, "copy-in thread: hipEventSynchronize");
             }
-            if (hipMemcpyAsync(hp.d_in[b], in + (size_t)i * slab_bytes, (size_t)steps_of(i) * step_bytes, hipMemcpyHostToDevice, hp.s_in) != hipSuccess ||
-                hipStreamSynchronize(hp.s_in) != hipSuccess) { failed.store(1); return; }
-            staged.store(i + 1);
+            if ((err = hipMemcpyAsync(hp.d_in[b], in + (size_t)i * slab_bytes, (size_t)steps_of(i) * step_bytes, hipMemcpyHostToDevice, hp.s_in)) != hipSuccess)
+                return ps.fail(err, "copy-in thread: hipMemcpyAsync (host to device)");
+            if ((err = hipStreamSynchronize(hp.s_in)) != hipSuccess) return ps.fail(err, "copy-in thread: hipStreamSynchronize");
+            ps.advance(ps.staged, i + 1);
         }
     });
     std::thread drainer([&] {
-        (void)hipSetDevice(dev);
+        hipError_t err;
+        if ((err = hipSetDevice(dev)) != hipSuccess) return ps.fail(err, "copy-out thread: hipSetDevice");
         for (int i = 0; i < n_slabs; ++i) {
             const int b = i & 1;
-            while (issued.load() < i + 1 && !failed.load()) std::this_thread::yield();
-            if (failed.load()) return;
-            if (hipStreamWaitEvent(hp.s_out, hp.ev_k[b], 0) != hipSuccess ||
-                hipMemcpyAsync(out + (size_t)i * slab_bytes, hp.d_out[b], (size_t)steps_of(i) * step_bytes, hipMemcpyDeviceToHost, hp.s_out) != hipSuccess ||
-                hipStreamSynchronize(hp.s_out) != hipSuccess) { failed.store(1); return; }
-            drained.store(i + 1);
+            if (!ps.wait_for(ps.issued, i + 1)) return;
+            if ((err = hipStreamWaitEvent(hp.s_out, hp.ev_k[b], 0)) != hipSuccess) return ps.fail(err, "copy-out thread: hipStreamWaitEvent");
+            if ((err = hipMemcpyAsync(out + (size_t)i * slab_bytes, hp.d_out[b], (size_t)steps_of(i) * step_bytes, hipMemcpyDeviceToHost, hp.s_out)) != hipSuccess)
+                return ps.fail(err, "copy-out thread: hipMemcpyAsync (device to host)");
+            if ((err = hipStreamSynchronize(hp.s_out)) != hipSuccess) return ps.fail(err, "copy-out thread: hipStreamSynchronize");
+            ps.advance(ps.drained, i + 1);
         }
     });
     int rc = ADSP_OK;
-    hipError_t herr = hipSuccess;
-    for (int i = 0; i < n_slabs && !failed.load(); ++i) {
+    for (int i = 0; i < n_slabs; ++i) {
         const int b = i & 1;
-        while (staged.load() < i + 1 && !failed.load()) std::this_thread::yield();  // (the copy-in thread synchronised its stream: the data is there)
-        while (drained.load() < i - 1 && !failed.load()) std::this_thread::yield();  // d_out[b] has been copied out (slab i - 2)
-        if (failed.load()) break;
-        if ((rc = adsp_apply_device(e, hp.d_in[b], hp.d_out[b], steps_of(i), hp.s_k))) break;
-        if ((herr = hipEventRecord(hp.ev_k[b], hp.s_k)) != hipSuccess) break;
-        issued.store(i + 1);
+        if (!ps.wait_for(ps.staged, i + 1)) break;   // (the copy-in thread synchronised its stream: the data is there)
+        if (!ps.wait_for(ps.drained, i - 1)) break;  // d_out[b] has been copied out (slab i - 2)
+        if ((rc = adsp_apply_device(e, hp.d_in[b], hp.d_out[b], steps_of(i), hp.s_k))) {
+            ps.fail(hipSuccess, "launch thread");
+            break;
+        }
+        const hipError_t herr = hipEventRecord(hp.ev_k[b], hp.s_k);
+        if (herr != hipSuccess) {
+            ps.fail(herr, "launch thread: hipEventRecord");
+            break;
+        }
+        ps.advance(ps.issued, i + 1);
     }
-    if (rc != ADSP_OK || herr != hipSuccess) failed.store(1);
     stager.join();
     drainer.join();
     (void)hipStreamSynchronize(hp.s_k);
-    if (rc) return rc;
-    if (herr != hipSuccess) return fail(ADSP_ERR_HIP, "pipelined host call: %s", hipGetErrorString(herr));
-    if (failed.load()) return fail(ADSP_ERR_HIP, "pipelined host call: a copy failed: %s", hipGetErrorString(hipGetLastError()));
+    if (rc) return rc;  // (adsp_apply_device left its own message)
+    if (ps.failed) return fail(ADSP_ERR_HIP, "pipelined host call: %s failed: %s", ps.where, hipGetErrorString(ps.err));
     return ADSP_OK;
 }
 
@@ -2298,63 +2363,64 @@ int apply_host_pipelined(adsp_engine* e, const char* in, char* out, int n_steps)
     int copy_threads = hw >= 16 ? 4 : hw >= 8 ? 2 : 1;
     if (const char* t = getenv("ADSP_HOST_COPY_THREADS")) copy_threads = atoi(t) > 0 && atoi(t) <= 32 ? atoi(t) : copy_threads;  // (tuning)
     auto steps_of = [&](int i) { return i + 1 < n_slabs ? slab_steps : n_steps - i * slab_steps; };
-    std::atomic<int> staged{0}, issued{0}, drained{0}, failed{0};
+    PipeSync ps;
     // stager: slab i -> pin_in[i % 2] once the H2D copy of slab i - 2 has left it
     std::thread stager([&] {
-        (void)hipSetDevice(dev);
-        for (int i = 0; i < n_slabs && !failed.load(); ++i) {
+        hipError_t err;
+        if ((err = hipSetDevice(dev)) != hipSuccess) return ps.fail(err, "staging thread: hipSetDevice");
+        for (int i = 0; i < n_slabs; ++i) {
             const int b = i & 1;
             if (i >= 2) {
-                while (issued.load() < i - 1 && !failed.load()) std::this_thread::yield();  // (its copy has been enqueued: the event is recorded)
-                if (failed.load()) return;
-                if (hipEventSynchronize(hp.ev_in[b]) != hipSuccess) { failed.store(1); return; }
+                if (!ps.wait_for(ps.issued, i - 1)) return;  // (its copy has been enqueued: the event is recorded)
+                if ((err = hipEventSynchronize(hp.ev_in[b])) != hipSuccess) return ps.fail(err, "staging thread: hipEventSynchronize");
             }
             parallel_memcpy(hp.pin_in[b], in + (size_t)i * slab_bytes, (size_t)steps_of(i) * step_bytes, copy_threads);
-            staged.store(i + 1);
+            ps.advance(ps.staged, i + 1);
         }
     });
     // drainer: pin_out[i % 2] -> the caller's array once the D2H copy of slab i has landed
     std::thread drainer([&] {
-        (void)hipSetDevice(dev);
+        hipError_t err;
+        if ((err = hipSetDevice(dev)) != hipSuccess) return ps.fail(err, "draining thread: hipSetDevice");
         for (int i = 0; i < n_slabs; ++i) {
             const int b = i & 1;
-            while (issued.load() < i + 1 && !failed.load()) std::this_thread::yield();
-            if (failed.load()) return;
-            if (hipEventSynchronize(hp.ev_out[b]) != hipSuccess) { failed.store(1); return; }
+            if (!ps.wait_for(ps.issued, i + 1)) return;
+            if ((err = hipEventSynchronize(hp.ev_out[b])) != hipSuccess) return ps.fail(err, "draining thread: hipEventSynchronize");
             parallel_memcpy(out + (size_t)i * slab_bytes, hp.pin_out[b], (size_t)steps_of(i) * step_bytes, copy_threads);
-            drained.store(i + 1);
+            ps.advance(ps.drained, i + 1);
         }
     });
     int rc = ADSP_OK;
     hipError_t herr = hipSuccess;
-    for (int i = 0; i < n_slabs && rc == ADSP_OK && herr == hipSuccess && !failed.load(); ++i) {
+    const char* at = "";
+    for (int i = 0; i < n_slabs && rc == ADSP_OK && herr == hipSuccess; ++i) {
         const int b = i & 1, ns = steps_of(i);
         const size_t bytes = (size_t)ns * step_bytes;
-        while (staged.load() < i + 1 && !failed.load()) std::this_thread::yield();
-        if (failed.load()) break;
+        if (!ps.wait_for(ps.staged, i + 1)) break;
         // d_in[b] was read by the kernel (and the ring update) of slab i - 2; pin_out[b] / d_out[b] must have been drained of slab i - 2
+        at = "launch thread: copy in";
         if (i >= 2 && (herr = hipStreamWaitEvent(hp.s_in, hp.ev_k[b], 0)) != hipSuccess) break;
         if ((herr = hipMemcpyAsync(hp.d_in[b], hp.pin_in[b], bytes, hipMemcpyHostToDevice, hp.s_in)) != hipSuccess) break;
         if ((herr = hipEventRecord(hp.ev_in[b], hp.s_in)) != hipSuccess) break;
         if ((herr = hipStreamWaitEvent(hp.s_k, hp.ev_in[b], 0)) != hipSuccess) break;
         if (i >= 2 && (herr = hipStreamWaitEvent(hp.s_k, hp.ev_out[b], 0)) != hipSuccess) break;  // d_out[b]: the D2H copy of slab i - 2 is done
         if ((rc = adsp_apply_device(e, hp.d_in[b], hp.d_out[b], ns, hp.s_k))) break;
+        at = "launch thread: copy out";
         if ((herr = hipEventRecord(hp.ev_k[b], hp.s_k)) != hipSuccess) break;
-        while (drained.load() < i - 1 && !failed.load()) std::this_thread::yield();  // pin_out[b] has been copied out (slab i - 2)
+        if (!ps.wait_for(ps.drained, i - 1)) break;  // pin_out[b] has been copied out (slab i - 2)
         if ((herr = hipStreamWaitEvent(hp.s_out, hp.ev_k[b], 0)) != hipSuccess) break;
         if ((herr = hipMemcpyAsync(hp.pin_out[b], hp.d_out[b], bytes, hipMemcpyDeviceToHost, hp.s_out)) != hipSuccess) break;
         if ((herr = hipEventRecord(hp.ev_out[b], hp.s_out)) != hipSuccess) break;
-        issued.store(i + 1);
+        ps.advance(ps.issued, i + 1);
     }
-    if (rc != ADSP_OK || herr != hipSuccess) failed.store(1);
+    if (rc != ADSP_OK || herr != hipSuccess) ps.fail(herr, at);
     stager.join();
     drainer.join();
     (void)hipStreamSynchronize(hp.s_in);
     (void)hipStreamSynchronize(hp.s_k);
     (void)hipStreamSynchronize(hp.s_out);
     if (rc) return rc;
-    if (herr != hipSuccess) return fail(ADSP_ERR_HIP, "pipelined host call: %s", hipGetErrorString(herr));
-    if (failed.load()) return fail(ADSP_ERR_HIP, "pipelined host call: a copy stream failed: %s", hipGetErrorString(hipGetLastError()));
+    if (ps.failed) return fail(ADSP_ERR_HIP, "pipelined host call: %s failed: %s", ps.where, hipGetErrorString(ps.err));
     return ADSP_OK;
 }
 }  // namespace

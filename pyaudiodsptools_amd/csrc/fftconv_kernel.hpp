@@ -71,6 +71,12 @@
 #define ADSP_PERSIST 0
 #endif
 
+// Both switches change what the kernels compute or how they take their arguments: they exist in the tuning library only
+// (make tuning -> libadsp_tuning.so, -DADSP_TUNING_BUILD; tools/build_ablations.sh).  A product build that sets one does not compile.
+#if (ADSP_ABLATE != 0 || ADSP_PERSIST != 0) && !defined(ADSP_TUNING_BUILD)
+#error "ADSP_ABLATE / ADSP_PERSIST are tuning switches (wrong results by construction / another argument convention): build them with `make tuning` (-DADSP_TUNING_BUILD), never into libadsp.so"
+#endif
+
 namespace adsp {
 
 struct KernelArgs {

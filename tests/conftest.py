@@ -1,8 +1,14 @@
 import os
 import sys
 
-import numpy as np
-import pytest
+# numpy.convolve (the oracle's float64 direct sum) is hundreds of thousands of short OpenBLAS dot products; with OpenBLAS's spinning
+# thread pool each of them needs every pool thread scheduled, and on a box whose cores are busy (a build running beside the tests) the
+# suite then crawls for tens of minutes.  One BLAS thread is as fast on a quiet box and immune to that.
+for _var in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_var, "1")
+
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
@@ -12,6 +18,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    try:  # numpy may have been imported (by a plugin) before the variables above were set
+        import threadpoolctl
+        config._adsp_blas_limit = threadpoolctl.threadpool_limits(limits=1, user_api="blas")
+    except Exception:
+        pass
 
 
 def load_golden(name):

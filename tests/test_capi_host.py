@@ -357,3 +357,28 @@ def test_upols_block_sizes_are_reported_without_a_gpu():
     assert lib.adsp_upols_block_sizes(sizes, 4) == 2 and list(sizes[:2]) == [8192, 16384] and lib.adsp_upols_block_size() == 8192
     one = (ctypes.c_int * 1)()
     assert lib.adsp_upols_block_sizes(one, 1) == 2 and one[0] == 8192   # a short array is filled as far as it goes
+
+
+def test_product_library_has_no_tuning_scaffolding():
+    """the A/B plan variants, the ablation switches and the persistent-block kernels live in libadsp_tuning.so
+    (`make tuning`); the product library says what it is, refuses ADSP_PLAN_VARIANT with a message, and its Makefile rule takes no
+    EXTRA flags (a stray EXTRA=-DADSP_ABLATE=... cannot change what libadsp.so computes; the macros do not even compile there)."""
+    import subprocess
+    import sys
+    from pyaudiodsptools_amd import _capi
+    lib = _capi.load()
+    assert lib.adsp_build_info() == b"product"
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['ADSP_PLAN_VARIANT'] = '22'\n"
+            "from pyaudiodsptools_amd import _capi\n"
+            "lib = _capi.load(); rc = lib.adsp_plan_supported(4096, 8192); print(rc, lib.adsp_last_error().decode())\n"
+            "os.environ['ADSP_PLAN_VARIANT'] = ''; print(lib.adsp_plan_supported(4096, 8192))" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.splitlines()
+    assert out[0].startswith("-3 ") and "libadsp_tuning.so" in out[0] and "make" in out[0], out
+    assert out[1].strip() == "0", "an EMPTY ADSP_PLAN_VARIANT is 'not set'"
+    symbols = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    mk = open(os.path.join(ROOT, "pyaudiodsptools_amd", "csrc", "Makefile")).read()
+    product_rule = mk[mk.index("%.o: %.hip"):mk.index("tuning:")]
+    assert "$(EXTRA)" not in product_rule and "plans_var" not in mk[mk.index("SRC"):mk.index("OBJ")]
+    hdr = open(os.path.join(ROOT, "pyaudiodsptools_amd", "csrc", "fftconv_kernel.hpp")).read()
+    assert "#error" in hdr and "ADSP_TUNING_BUILD" in hdr
+    assert symbols.count(" T adsp_") == len(_capi.SIGNATURES)

@@ -193,7 +193,7 @@ def test_bench_two_ranks_on_one_gpu_real_engine():
     cfgs = d["configs"]
     assert set(cfgs) >= {"config4_highcut_8192ch_x_4096", "config5_chain_4096ch_x_8192_96k"}
     for c in cfgs.values():
-        assert c["value"] > 0 and c["n_gpus"] == 2 and c["roofline_frac"] > 0
+        assert c["value"] > 0 and c["n_gpus"] == 2 and c["roofline"]["frac"] > 0
 
 
 def test_bench_single_process_mode_one_gpu():

