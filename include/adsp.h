@@ -229,6 +229,11 @@ ADSP_API int adsp_effect_device(int device_id, int effect, float p0, float p1, f
                                 float* d_out, size_t n, void* stream);
 ADSP_API int adsp_effect_host(int device_id, int effect, float p0, float p1, float p2, int phase, const float* in,
                               float* out, size_t n);
+/* The tremolo over a [rows][row_len] device batch whose rows are the chunks of `rows` channels of ONE step: every row starts at LFO
+ * table index `phase` (the reference runs one CreateTremolo per channel, all in step: EffectTremolo.py:27-47).  What engines that
+ * cannot fuse the effect (one engine pass per kernel slice) run behind their last pass.  In place allowed. */
+ADSP_API int adsp_tremolo_rows_device(int device_id, float depth, float lfo_per_sample, int lfo_length, int phase, const float* d_in,
+                                      float* d_out, int rows, int row_len, void* stream);
 /* MixSignals (Utility.py:51-72): out[i] = sum_j inputs[j][i], clipped to [-1, 1] when clip != 0.  `inputs` is a HOST
  * array of k device (adsp_mix_device) or host (adsp_mix_host) pointers; out may alias an input when k <= 8. */
 ADSP_API int adsp_mix_device(int device_id, const float* const* d_inputs, int k, int clip, float* d_out, size_t n, void* stream);
@@ -534,7 +539,8 @@ ADSP_API int adsp_exact_apply_host(adsp_exact* fir, const void* in, void* out, i
  *             kernel by 0..3 taps).  chunk_size: multiple of 4, >= 16.  Batches: [step][channel][sample] like everything else.
  *   max_steps: chunks one pair of launches covers at most (longer calls are split); sizes the delay line:
  *             (ceil((max_steps * chunk_size + delay) / B) + n_partitions + 3) blocks of 8 B bytes per channel.
- * A stateless fused effect (ADSP_EFFECT_* except the tremolo; float32 engines) is applied to the output registers.
+ * A fused effect (ADSP_EFFECT_*; float32 engines) is applied to the output registers; the tremolo's LFO follows the stream's own time
+ * base (table index 0 at the first sample after adsp_upols_set_epilogue / adsp_upols_reset, the reference's buffer quirk included).
  * Calls of one engine are ordered by the library whatever streams they are given (a call on another stream than the previous one
  * first waits for an event recorded behind the previous call's launches); one host thread per engine at a time.
  * After every call the engine keeps only the LAST 2B samples of the input it was given (no later window reaches further back).
@@ -560,6 +566,15 @@ ADSP_API int adsp_upols_info(const adsp_upols* fir, int* history_chunks, int* de
 /* d_in / d_out: device [n_steps][n_channels][chunk_size], NOT aliased; asynchronous on `stream` */
 ADSP_API int adsp_upols_apply_device(adsp_upols* fir, const void* d_in, void* d_out, int n_steps, void* stream);
 ADSP_API int adsp_upols_apply_host(adsp_upols* fir, const void* in, void* out, int n_steps);
+/* The filter of a running engine (same partitioning: n_partitions x (block + 1) interleaved bins): replace it (set-up path: drains
+ * the device), read back what the tables were last built from, or take it over from another engine / rank - SURVEY 8e's ONE collective
+ * for kernels longer than a transform.  adsp_upols_bcast_spectra: one process, one engine per GPU (like adsp_bcast_spectrum);
+ * adsp_upols_bcast_spectra_rank: one process per GPU, `unique_id` from adsp_rccl_unique_id on rank 0 (like adsp_bcast_spectrum_rank).
+ * The payload carries (chunk, block, partitions, delay, format): an engine partitioned differently keeps its own filter and fails. */
+ADSP_API int adsp_upols_set_spectra(adsp_upols* fir, const float* spectra);
+ADSP_API int adsp_upols_get_spectra(const adsp_upols* fir, float* spectra, size_t n_floats);
+ADSP_API int adsp_upols_bcast_spectra(adsp_upols* const* engines, int n, int root);
+ADSP_API int adsp_upols_bcast_spectra_rank(adsp_upols* fir, const char* unique_id, int rank, int world, int root);
 /* wait until everything this engine has launched - on `stream` or, if its last call went elsewhere, there - has finished */
 ADSP_API int adsp_upols_synchronize(adsp_upols* fir, void* stream);
 /* Checkpoint / resume (the reference's whole state is its two previous chunks, EffectFFTFilter.py:40-42 - a partitioned

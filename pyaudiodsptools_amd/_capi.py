@@ -81,6 +81,8 @@ SIGNATURES = {
                                           ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "adsp_effect_host": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                         ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "adsp_tremolo_rows_device": (ctypes.c_int, [ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "adsp_mix_device": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
                                        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "adsp_mix_host": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
@@ -121,6 +123,10 @@ SIGNATURES = {
     "adsp_upols_info": (ctypes.c_int, [ctypes.c_void_p, _c_int_p, _c_int_p, ctypes.POINTER(ctypes.c_size_t)]),
     "adsp_upols_apply_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "adsp_upols_apply_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    "adsp_upols_set_spectra": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "adsp_upols_get_spectra": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "adsp_upols_bcast_spectra": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]),
+    "adsp_upols_bcast_spectra_rank": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "adsp_upols_synchronize": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "adsp_upols_state_bytes": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]),
     "adsp_upols_get_state": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
@@ -194,7 +200,12 @@ def load():
         pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        try:
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        except AttributeError:
+            if not os.environ.get("ADSP_LIB"):
+                raise
+            continue  # a tuning library (ADSP_LIB) built before this entry point existed: A/B runs do not call it
         fn.restype = restype
         fn.argtypes = argtypes
     if lib.adsp_version() != ADSP_ABI_VERSION:

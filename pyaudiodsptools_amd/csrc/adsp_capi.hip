@@ -73,6 +73,21 @@ __global__ void adsp_pointwise_kernel(const float* __restrict__ in, float* __res
     for (; i < n; i += stride) out[i] = adsp::epilogue_value(in[i], op, p0, p1, p2);
 }
 
+// The tremolo over a [rows][row_len] batch whose every row is one channel's chunk: all rows start at LFO table index `phase` (the
+// reference runs one tremolo device per channel, all in step: EffectTremolo.py:40-46).  blockIdx.y = row.
+__global__ void adsp_tremolo_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int row_len, float depth, float rev_per_sample,
+                                         int len, int phase) {
+    const size_t row = static_cast<size_t>(blockIdx.y) * row_len;
+    const float inv_len = 1.f / static_cast<float>(len);
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < row_len; r += gridDim.x * blockDim.x) {
+        int idx = phase + r;  // < 2^24 + 2^23
+        idx -= static_cast<int>(static_cast<float>(idx) * inv_len) * len;
+        idx += idx < 0 ? len : 0;
+        idx -= idx >= len ? len : 0;
+        out[row + r] = in[row + r] * adsp::tremolo_gain(idx, depth, rev_per_sample);
+    }
+}
+
 // MixSignals (Utility.py:51-72): out = clip(sum of k signals) - up to 8 addends per pass
 struct MixArgs {
     const float* in[8];
@@ -1105,6 +1120,20 @@ int adsp_effect_device(int device_id, int effect, float p0, float p1, float p2, 
                        float* d_out, size_t n, void* stream) {
     if (!d_in || !d_out) return fail(ADSP_ERR_ARG, "NULL argument");
     return pointwise_launch(device_id, effect, p0, p1, p2, phase, d_in, d_out, n, (hipStream_t)stream);
+}
+
+int adsp_tremolo_rows_device(int device_id, float depth, float lfo_per_sample, int lfo_length, int phase, const float* d_in, float* d_out, int rows,
+                             int row_len, void* stream) {
+    if (!d_in || !d_out) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (rows < 1 || rows > 65535 || row_len < 1 || row_len > (1 << 24)) return fail(ADSP_ERR_ARG, "rows 1..65535 of 1..2^24 samples");
+    if (lfo_length < 1 || lfo_length > (1 << 23) || phase < 0 || phase >= lfo_length) return fail(ADSP_ERR_ARG, "tremolo: table length 1..2^23, 0 <= phase < length");
+    HIP_TRY(hipSetDevice(device_id));
+    unsigned bx = (unsigned)((row_len + 255) / 256);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(adsp_tremolo_rows_kernel, dim3(bx, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, d_in, d_out, row_len, depth, lfo_per_sample,
+                       lfo_length, phase);
+    HIP_TRY(hipGetLastError());
+    return ADSP_OK;
 }
 
 int adsp_mix_device(int device_id, const float* const* d_inputs, int k, int clip, float* d_out, size_t n, void* stream) {

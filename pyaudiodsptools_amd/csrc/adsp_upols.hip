@@ -43,12 +43,23 @@
 
 using adsp::fail;
 
+namespace adsp {  // adsp_rccl.hip
+int rccl_broadcast(float* const* d_buf, const int* devs, const hipStream_t* streams, int n, size_t count, int root);
+int rccl_broadcast_rank(const char* unique_id, int rank, int world, int root, int dev, float* d_buf, size_t count, hipStream_t stream);
+}  // namespace adsp
+
 // tuning (tools/sessions/r5_session12.sh): stages of the multiply kernel requested ahead, and its workgroups per CU
 #ifndef ADSP_UPOLS_AHEAD
 #define ADSP_UPOLS_AHEAD 4
 #endif
 #ifndef ADSP_UPOLS_MAC_WAVES
 #define ADSP_UPOLS_MAC_WAVES 2
+#endif
+#ifndef ADSP_UPOLS_ABLATE  // tuning builds only (make tuning EXTRA=-DADSP_UPOLS_ABLATE=<mask>): 1 no table loads, 2 no spectrum loads, 4 table entries (c1, c2, c4) not formed
+#define ADSP_UPOLS_ABLATE 0
+#endif
+#if ADSP_UPOLS_ABLATE != 0 && !defined(ADSP_TUNING_BUILD)
+#error "ADSP_UPOLS_ABLATE changes what the kernels compute: tuning builds only (make tuning)"
 #endif
 
 namespace adsp {
@@ -79,6 +90,8 @@ struct UpolsArgs {
     int mac_grid;        // workgroups of the multiply-accumulate proper
     int tail;            // samples per channel to keep: min(2B, n_steps N) - no later window reaches further back (multiple of 4)
     int cnt;             // chunks of this call that enter the ring: min(n_steps, nh)
+    int epi_phase;       // fused tremolo (EffectTremolo.py:27-47): LFO table index of the call's first output sample ...
+    int epi_replay;      // ... or, 1: every chunk replays the table from epi_phase (the reference's buffer quirk, adsp_capi.hip: tremolo_run)
 };
 
 namespace {
@@ -318,10 +331,18 @@ __global__ __launch_bounds__(PL::T, ADSP_UPOLS_MAC_WAVES) void upols_mac_kernel(
     auto request = [&](Stage& s, const float2* z, const float4* tab, int h) {
         const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(tab), 0, R * T * 16, 0x00020000);
         const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(z), 0, static_cast<int>(kSlot) * 8, 0x00020000);
+#if defined(ADSP_TUNING_BUILD) && (ADSP_UPOLS_ABLATE & 1)  // tuning (wrong results): no table traffic - the bound of sharing table fetches between channels
+        s.t0 = s.t1 = make_float4(1.f, 0.f, 0.5f, 0.f);
+#else
         s.t0 = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rt, lane16, (2 * h) * T * 16, 0));
         s.t1 = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rt, lane16, (2 * h + 1) * T * 16, 0));
+#endif
+#if defined(ADSP_TUNING_BUILD) && (ADSP_UPOLS_ABLATE & 2)  // ... no spectrum traffic
+        s.za = s.zb = make_float4(0.25f, 0.5f, 0.75f, 1.f);
+#else
         s.za = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rz, lane16, (2 * h) * T * 16, 0));
         s.zb = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rz, lane16, (2 * h + 1) * T * 16, 0));
+#endif
     };
     // The matrix entries c1 = 2s + 2d Re(wc), c2 = -2i d Im(wc), c4 = 2s - 2d Re(wc) are formed here: the twiddle wc = -i exp(-i pi k / M) of
     // bin k = tid + (M / R) r does not depend on the partition - (cos, sin)(pi tid / M) in two registers, (cos, sin)(pi r / R) literals - so the
@@ -393,7 +414,35 @@ __global__ __launch_bounds__(PL::T, ADSP_UPOLS_MAC_WAVES) void upols_mac_kernel(
     upols_indices<PL>(tid, ja, jb);
     run_passes<PL, true, 0, const real4* __restrict__>(ai, ar, lds, a.tw, tid, ja, jb);  // inverse = forward on swapped parts
 
-    if (a.epi_op != 0) {  // wave-uniform: a stateless effect on the kept half (Saturator, SoftClipper, HardDistortion, Volume, BitCrusher)
+    if (a.epi_op == ADSP_EFFECT_TREMOLO) {
+        // the LFO's time base is the stream's own: register m of thread tid holds output times tau, tau + 1 with
+        // tau = rel_first + (blk - 1) M + 2 (tid + T m) relative to the call's first sample, whose table index is epi_phase -
+        // the same for every channel, as the reference's one-device-per-channel loop has it (EffectTremolo.py:40-46)
+        const int len = static_cast<int>(a.epi_p2);
+        const float inv_len = 1.f / a.epi_p2, inv_n = a.inv_n;
+        const int tau0 = a.rel_first + blk * PL::M - PL::M + 2 * tid;
+        if (a.epi_replay) {
+            int r0 = tau0 % a.N;  // (negative for samples that are not stored)
+            r0 += r0 < 0 ? a.N : 0;
+#pragma unroll
+            for (int m = P / 2; m < P; ++m) {
+                const int r = small_mod(r0 + 2 * T * m, a.N, inv_n);
+                const int r1 = r + 1 == a.N ? 0 : r + 1;
+                ar[m] *= tremolo_gain(small_mod(a.epi_phase + r, len, inv_len), a.epi_p0, a.epi_p1);
+                ai[m] *= tremolo_gain(small_mod(a.epi_phase + r1, len, inv_len), a.epi_p0, a.epi_p1);
+            }
+        } else {
+            int base = (a.epi_phase + tau0) % len;
+            base += base < 0 ? len : 0;
+#pragma unroll
+            for (int m = P / 2; m < P; ++m) {
+                const int n = small_mod(base + 2 * T * m, len, inv_len);
+                const int n1 = n + 1 == len ? 0 : n + 1;
+                ar[m] *= tremolo_gain(n, a.epi_p0, a.epi_p1);
+                ai[m] *= tremolo_gain(n1, a.epi_p0, a.epi_p1);
+            }
+        }
+    } else if (a.epi_op != 0) {  // wave-uniform: a stateless effect on the kept half (Saturator, SoftClipper, HardDistortion, Volume, BitCrusher)
 #pragma unroll
         for (int m = P / 2; m < P; ++m) {
             ar[m] = epilogue_value(ar[m], a.epi_op, a.epi_p0, a.epi_p1, a.epi_p2);
@@ -494,9 +543,14 @@ struct adsp_upols {
     int pair_stride, pair0_stride;
     int epi_op;
     float epi_p[3];
+    int lfo_len;             // fused tremolo: LFO table length and the length of the reference's LFO buffer (EffectTremolo.py:40-45): the
+    long long lfo_copy_len;  // effect's whole state
+    int epi_phase, epi_replay;
     bool prepared;
     char *stage_in, *stage_out;
     size_t stage_bytes;
+    std::vector<float>* spectra;  // host copy of the [P][B + 1] interleaved partition spectra the tables were built from (get / broadcast)
+    float* d_spectra;          // the same on the device, behind a 16-float header: the buffer of the RCCL broadcasts (allocated on first use)
     hipEvent_t ev_done;        // recorded behind every launch pair: a call on ANOTHER stream waits for it (the delay line and the ring are shared state)
     hipStream_t last_stream;
     bool launched;
@@ -507,6 +561,32 @@ struct adsp_upols {
 
 namespace {
 long long floor_div(long long a, long long b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+// adsp_capi.hip's tremolo_run for this engine: the reference's tremolo keeps a buffer of LFO tables and cuts each chunk off its front
+// (EffectTremolo.py:40-45); its length is the whole state, the next chunk starts at table index (-length) mod table; when the buffer
+// holds EXACTLY one chunk, `copy[-0:]` keeps all of it and every later chunk replays that segment.  Sets the phase / replay flag of
+// the next launch pair and returns how many of the next max_steps chunks run on contiguously.
+int upols_tremolo_run(adsp_upols* u, int max_steps) {
+    const long long N = u->cfg.chunk_size, L = u->lfo_len;
+    long long len = u->lfo_copy_len;
+    u->epi_replay = 0;
+    if (len == N) {
+        u->epi_replay = 1;
+        u->epi_phase = (int)((L - N % L) % L);
+        return max_steps;
+    }
+    while (len < N) len += L;
+    u->epi_phase = (int)((L - len % L) % L);
+    int run = 0;
+    while (run < max_steps) {
+        while (len < N) len += L;
+        ++run;
+        if (len == N) break;
+        len -= N;
+    }
+    u->lfo_copy_len = len;
+    return run;
+}
 
 int upols_launch_pair(adsp_upols* u, const void* d_in, void* d_out, int n, hipStream_t stream) {
     const adsp_upols_config& c = u->cfg;
@@ -541,6 +621,8 @@ int upols_launch_pair(adsp_upols* u, const void* d_in, void* d_out, int n, hipSt
     a.epi_p0 = u->epi_p[0];
     a.epi_p1 = u->epi_p[1];
     a.epi_p2 = u->epi_p[2];
+    a.epi_phase = u->epi_phase;
+    a.epi_replay = u->epi_replay;
     const long long groups = ((long long)c.n_channels + 7) / 8 * 8;
     const bool s16 = c.sample_format != ADSP_FORMAT_F32;
     // 1. forward: the blocks whose 2B-sample windows [(b-1)B, (b+1)B) this call completes
@@ -574,6 +656,50 @@ int upols_launch_pair(adsp_upols* u, const void* d_in, void* d_out, int n, hipSt
     HIP_TRY(hipLaunchKernel(pl.mac[s16 ? 1 : 0], dim3((unsigned)(grid + c.n_channels)), dim3(pl.threads), kargs, pl.lds_bytes, stream));
     u->ring_pos = (u->ring_pos + cnt) % u->ring_slots;
     u->steps_done += n;
+    return ADSP_OK;
+}
+}  // namespace
+
+
+namespace {
+size_t upols_spectra_floats(const adsp_upols* u) { return (size_t)u->cfg.n_partitions * 2 * ((size_t)u->plan->block + 1); }
+
+// Host spectra -> the multiply launch's tables (allocated on first use; later calls - adsp_upols_set_spectra, a broadcast - overwrite
+// them: the caller has drained the device).  Per partition: tab0 = the (c1, c2, c4) entries of thread 0's self-paired butterflies, built
+// like an engine's (build_pair_tables); the regular pairs as (2s, 2d) - pair r of thread t is the bins k = t + (M / R) r and M - k
+// (table_build.hpp: pair_entry):  g1 = H[k] / 4M, g2 = conj(H[M-k]) / 4M, s = g1 + g2, d = g1 - g2;  the kernel forms c1, c2, c4 from
+// them and the bin's twiddle.
+int upols_upload_tables(adsp_upols* u, const float* spectra) {
+    const adsp_upols_config* cfg = &u->cfg;
+    const PlanInfo pl = u->plan->shape;
+    const int kB = u->plan->block;
+    std::vector<float4> tab, all;
+    std::vector<float2> tab0, all0;
+    const int RR = pl.rad[pl.NP - 1], D = kB / RR, T = pl.T;
+    if (pl.XL || pl.P / RR != 2) return fail(ADSP_ERR_STATE, "internal: the partitioned engines run in-register pairing plans with one pair of butterflies per thread");
+    u->pair_stride = RR * T;
+    all.resize((size_t)cfg->n_partitions * u->pair_stride);
+    for (int p = 0; p < cfg->n_partitions; ++p) {
+        const float* H = spectra + (size_t)p * 2 * (kB + 1);
+        build_pair_tables<float, float>(pl, kB, H, false, tab, tab0);
+        if (p == 0) u->pair0_stride = (int)tab0.size();
+        all0.insert(all0.end(), tab0.begin(), tab0.end());
+        const double sc = 1.0 / (4.0 * (double)kB);
+        for (int r = 0; r < RR; ++r)
+            for (int t = 0; t < T; ++t) {
+                const int k = t + D * r;
+                const double g1r = (double)H[2 * k] * sc, g1i = (double)H[2 * k + 1] * sc;
+                const double g2r = (double)H[2 * (kB - k)] * sc, g2i = -(double)H[2 * (kB - k) + 1] * sc;
+                all[(size_t)p * u->pair_stride + (size_t)r * T + t] =
+                    make_float4((float)(2.0 * (g1r + g2r)), (float)(2.0 * (g1i + g2i)), (float)(2.0 * (g1r - g2r)), (float)(2.0 * (g1i - g2i)));
+            }
+    }
+    if (!u->pair) HIP_TRY(hipMalloc(&u->pair, all.size() * sizeof(float4)));
+    if (!u->pair0) HIP_TRY(hipMalloc(&u->pair0, all0.size() * sizeof(float2)));
+    HIP_TRY(hipMemcpy(u->pair, all.data(), all.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(u->pair0, all0.data(), all0.size() * sizeof(float2), hipMemcpyHostToDevice));
+    if (!u->spectra) u->spectra = new std::vector<float>();
+    u->spectra->assign(spectra, spectra + upols_spectra_floats(u));
     return ADSP_OK;
 }
 }  // namespace
@@ -655,35 +781,8 @@ int adsp_upols_create(const adsp_upols_config* cfg, const float* spectra, adsp_u
     if ((err = hipMalloc(&u->tw, tw.size() * sizeof(float4))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
     if ((err = hipMemcpy(u->tw, tw.data(), tw.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess)
         return bail(fail(ADSP_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(err)));
-    // per partition: tab0 = the (c1, c2, c4) entries of thread 0's self-paired butterflies, built like an engine's (build_pair_tables);
-    // the regular pairs as (2s, 2d) - pair r of thread t is the bins k = t + (M / R) r and M - k (table_build.hpp: pair_entry):
-    //   g1 = H[k] / 4M, g2 = conj(H[M-k]) / 4M, s = g1 + g2, d = g1 - g2;  the kernel forms c1, c2, c4 from them and the bin's twiddle
-    std::vector<float4> tab, all;
-    std::vector<float2> tab0, all0;
-    const int RR = pl.rad[pl.NP - 1], D = kB / RR, T = pl.T;
-    if (pl.XL || pl.P / RR != 2) return bail(fail(ADSP_ERR_STATE, "internal: the partitioned engines run in-register pairing plans with one pair of butterflies per thread"));
-    u->pair_stride = RR * T;
-    all.resize((size_t)cfg->n_partitions * u->pair_stride);
-    for (int p = 0; p < cfg->n_partitions; ++p) {
-        const float* H = spectra + (size_t)p * 2 * (kB + 1);
-        build_pair_tables<float, float>(pl, kB, H, false, tab, tab0);
-        if (p == 0) u->pair0_stride = (int)tab0.size();
-        all0.insert(all0.end(), tab0.begin(), tab0.end());
-        const double sc = 1.0 / (4.0 * (double)kB);
-        for (int r = 0; r < RR; ++r)
-            for (int t = 0; t < T; ++t) {
-                const int k = t + D * r;
-                const double g1r = (double)H[2 * k] * sc, g1i = (double)H[2 * k + 1] * sc;
-                const double g2r = (double)H[2 * (kB - k)] * sc, g2i = -(double)H[2 * (kB - k) + 1] * sc;
-                all[(size_t)p * u->pair_stride + (size_t)r * T + t] =
-                    make_float4((float)(2.0 * (g1r + g2r)), (float)(2.0 * (g1i + g2i)), (float)(2.0 * (g1r - g2r)), (float)(2.0 * (g1i - g2i)));
-            }
-    }
-    if ((err = hipMalloc(&u->pair, all.size() * sizeof(float4))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
-    if ((err = hipMalloc(&u->pair0, all0.size() * sizeof(float2))) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMalloc: %s", hipGetErrorString(err)));
-    if ((err = hipMemcpy(u->pair, all.data(), all.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess ||
-        (err = hipMemcpy(u->pair0, all0.data(), all0.size() * sizeof(float2), hipMemcpyHostToDevice)) != hipSuccess)
-        return bail(fail(ADSP_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(err)));
+    const int rc_tab = upols_upload_tables(u, spectra);
+    if (rc_tab) return bail(rc_tab);
     *out = u;
     return ADSP_OK;
 }
@@ -695,6 +794,8 @@ void adsp_upols_destroy(adsp_upols* u) {
     for (void* p : {(void*)u->ring, (void*)u->zeros, (void*)u->tw, (void*)u->pair, (void*)u->pair0, (void*)u->zline, (void*)u->stage_in, (void*)u->stage_out})
         if (p) (void)hipFree(p);
     if (u->ev_done) (void)hipEventDestroy(u->ev_done);
+    if (u->d_spectra) (void)hipFree(u->d_spectra);
+    delete u->spectra;
     delete u;
 }
 
@@ -707,18 +808,23 @@ int adsp_upols_reset(adsp_upols* u) {
     u->ring_pos = u->ring_slots - 1;
     u->steps_done = 0;
     u->fwd_done = -1;
+    u->lfo_copy_len = u->lfo_len;  // ... and the fused tremolo's LFO restarts (EffectTremolo.py:49-57)
+    u->epi_phase = u->epi_replay = 0;
     return ADSP_OK;
 }
 
 int adsp_upols_set_epilogue(adsp_upols* u, int effect, float p0, float p1, float p2) {
     if (!u) return fail(ADSP_ERR_ARG, "NULL engine");
     if (effect < ADSP_EFFECT_NONE || effect > ADSP_EFFECT_BIT_CRUSHER) return fail(ADSP_ERR_ARG, "unknown effect %d", effect);
-    if (effect == ADSP_EFFECT_TREMOLO) return fail(ADSP_ERR_ARG, "the tremolo's per-channel time base is only available fused on a single-transform engine");
     if (effect != ADSP_EFFECT_NONE && u->cfg.sample_format != ADSP_FORMAT_F32) return fail(ADSP_ERR_ARG, "fused effects need a float32 engine");
+    if (effect == ADSP_EFFECT_TREMOLO && !(p2 >= 1.f && p2 <= 8388608.f)) return fail(ADSP_ERR_ARG, "tremolo: p2 = LFO table length in samples (1..2^23)");
     u->epi_op = effect;
     u->epi_p[0] = p0;
     u->epi_p[1] = p1;
     u->epi_p[2] = p2;
+    u->lfo_len = effect == ADSP_EFFECT_TREMOLO ? (int)p2 : 0;
+    u->lfo_copy_len = u->lfo_len;  // a fresh LFO: one table in the buffer (EffectTremolo.py:24)
+    u->epi_phase = u->epi_replay = 0;
     return ADSP_OK;
 }
 
@@ -743,7 +849,8 @@ int adsp_upols_apply_device(adsp_upols* u, const void* d_in, void* d_out, int n_
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (u->launched && st != u->last_stream) HIP_TRY(hipStreamWaitEvent(st, u->ev_done, 0));  // the previous call ran on another stream
     for (int done = 0; done < n_steps;) {  // at most max_steps chunks per launch pair (the delay line is sized for that)
-        const int n = n_steps - done < u->cfg.max_steps ? n_steps - done : u->cfg.max_steps;
+        int n = n_steps - done < u->cfg.max_steps ? n_steps - done : u->cfg.max_steps;
+        if (u->epi_op == ADSP_EFFECT_TREMOLO) n = upols_tremolo_run(u, n);  // the LFO runs on contiguously except where the reference's buffer quirk restarts it
         const int rc = upols_launch_pair(u, static_cast<const char*>(d_in) + (size_t)done * plane, static_cast<char*>(d_out) + (size_t)done * plane, n, st);
         if (rc) return rc;
         done += n;
@@ -768,7 +875,7 @@ struct UpolsStateHeader {
     unsigned magic, version;
     adsp_upols_config cfg;
     int ring_slots, R, ring_pos, reserved;
-    long long steps_done, fwd_done;
+    long long steps_done, fwd_done, lfo_copy_len;
     unsigned long long ring_bytes, zline_bytes;
 };
 constexpr unsigned kStateMagic = 0x55504f4cu;  // "UPOL"
@@ -797,6 +904,7 @@ int adsp_upols_get_state(adsp_upols* u, void* state, size_t capacity) {
     h.ring_pos = u->ring_pos;
     h.steps_done = u->steps_done;
     h.fwd_done = u->fwd_done;
+    h.lfo_copy_len = u->lfo_copy_len;
     h.ring_bytes = (size_t)u->ring_slots * u->plane_bytes();
     h.zline_bytes = u->zline_bytes();
     char* out = static_cast<char*>(state);
@@ -829,7 +937,111 @@ int adsp_upols_set_state(adsp_upols* u, const void* state, size_t bytes) {
     u->ring_pos = h.ring_pos;
     u->steps_done = h.steps_done;
     u->fwd_done = h.fwd_done;
+    if (u->lfo_len > 0 && h.lfo_copy_len >= 1 && h.lfo_copy_len <= (long long)u->lfo_len + c.chunk_size) u->lfo_copy_len = h.lfo_copy_len;
     return ADSP_OK;
+}
+
+// ---- the filter of a running engine: set / get / broadcast (the path's ONE collective, for kernels longer than a transform) ----
+int adsp_upols_set_spectra(adsp_upols* u, const float* spectra) {
+    if (!u || !spectra) return fail(ADSP_ERR_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(u->cfg.device_id));
+    HIP_TRY(hipDeviceSynchronize());  // launches in flight still read the old tables (set-up path)
+    return upols_upload_tables(u, spectra);
+}
+
+int adsp_upols_get_spectra(const adsp_upols* u, float* spectra, size_t n_floats) {
+    if (!u || !spectra) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (n_floats != upols_spectra_floats(u)) return fail(ADSP_ERR_ARG, "n_floats %zu != n_partitions x 2 (block + 1) = %zu", n_floats, upols_spectra_floats(u));
+    memcpy(spectra, u->spectra->data(), n_floats * sizeof(float));
+    return ADSP_OK;
+}
+
+namespace {
+constexpr int kUpolsHdr = 16;
+int upols_bcast_buffer(adsp_upols* u) {
+    if (!u->d_spectra) HIP_TRY(hipMalloc(&u->d_spectra, (kUpolsHdr + upols_spectra_floats(u)) * sizeof(float)));
+    return ADSP_OK;
+}
+void upols_header(const adsp_upols* u, float (&h)[kUpolsHdr]) {
+    const adsp_upols_config& c = u->cfg;
+    const float v[kUpolsHdr] = {(float)c.chunk_size, (float)c.block_size, (float)c.n_partitions, (float)c.delay, (float)c.sample_format, 0.f, 0.f, 0.f,
+                                0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    memcpy(h, v, sizeof v);
+}
+// after a collective: the buffer's header must describe THIS engine (a spectrum only means something with the partitioning it was
+// designed for); then the tables are rebuilt from what arrived
+int upols_adopt(adsp_upols* u, int who) {
+    const size_t n = upols_spectra_floats(u);
+    std::vector<float> host(kUpolsHdr + n);
+    HIP_TRY(hipMemcpy(host.data(), u->d_spectra, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+    float mine[kUpolsHdr];
+    upols_header(u, mine);
+    for (int i = 0; i < 5; ++i)
+        if (host[i] != mine[i])
+            return fail(ADSP_ERR_ARG, "engine %d: partitioning (chunk %d, block %d, %d partitions, delay %d, format %d) differs from the root's (%d, %d, %d, %d, %d); "
+                        "this engine keeps its own filter", who, (int)mine[0], (int)mine[1], (int)mine[2], (int)mine[3], (int)mine[4], (int)host[0], (int)host[1],
+                        (int)host[2], (int)host[3], (int)host[4]);
+    HIP_TRY(hipDeviceSynchronize());
+    return upols_upload_tables(u, host.data() + kUpolsHdr);
+}
+int upols_stage_root(adsp_upols* u) {
+    float h[kUpolsHdr];
+    upols_header(u, h);
+    HIP_TRY(hipMemcpy(u->d_spectra, h, sizeof h, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(u->d_spectra + kUpolsHdr, u->spectra->data(), upols_spectra_floats(u) * sizeof(float), hipMemcpyHostToDevice));
+    return ADSP_OK;
+}
+}  // namespace
+
+// ONE process, one engine per GPU (ncclCommInitAll inside libadsp): every engine takes over engines[root]'s filter
+int adsp_upols_bcast_spectra(adsp_upols* const* engines, int n, int root) {
+    if (!engines || n < 1) return fail(ADSP_ERR_ARG, "need at least one engine");
+    if (root < 0 || root >= n) return fail(ADSP_ERR_ARG, "root %d out of range 0..%d", root, n - 1);
+    for (int i = 0; i < n; ++i) {
+        if (!engines[i]) return fail(ADSP_ERR_ARG, "engine %d is NULL", i);
+        for (int j = 0; j < i; ++j)
+            if (engines[j] == engines[i] || engines[j]->cfg.device_id == engines[i]->cfg.device_id)
+                return fail(ADSP_ERR_ARG, "engines %d and %d share device %d: one engine per GPU (RCCL ranks are devices)", j, i, engines[i]->cfg.device_id);
+        if (upols_spectra_floats(engines[i]) != upols_spectra_floats(engines[root]))
+            return fail(ADSP_ERR_ARG, "engine %d is partitioned differently from the root engine", i);
+    }
+    std::vector<float*> bufs(n);
+    std::vector<int> devs(n);
+    std::vector<hipStream_t> streams(n, nullptr);
+    for (int i = 0; i < n; ++i) {
+        HIP_TRY(hipSetDevice(engines[i]->cfg.device_id));
+        int rc = upols_bcast_buffer(engines[i]);
+        if (rc) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+        bufs[i] = engines[i]->d_spectra;
+        devs[i] = engines[i]->cfg.device_id;
+    }
+    HIP_TRY(hipSetDevice(engines[root]->cfg.device_id));
+    int rc = upols_stage_root(engines[root]);
+    if (rc) return rc;
+    if ((rc = adsp::rccl_broadcast(bufs.data(), devs.data(), streams.data(), n, kUpolsHdr + upols_spectra_floats(engines[root]), root))) return rc;
+    for (int i = 0; i < n; ++i) {
+        HIP_TRY(hipSetDevice(engines[i]->cfg.device_id));
+        HIP_TRY(hipDeviceSynchronize());
+        if ((rc = upols_adopt(engines[i], i))) return rc;
+    }
+    return ADSP_OK;
+}
+
+// One process per GPU (ncclCommInitRank, the id from adsp_rccl_unique_id on rank 0).  Every rank enters the one collective whatever it
+// thinks of its own engine: sizes are fixed by the caller's (chunk, block, partitions), a mismatch shows in the header afterwards.
+int adsp_upols_bcast_spectra_rank(adsp_upols* u, const char* unique_id, int rank, int world, int root) {
+    if (!u || !unique_id) return fail(ADSP_ERR_ARG, "NULL argument");
+    if (world < 1 || rank < 0 || rank >= world || root < 0 || root >= world)
+        return fail(ADSP_ERR_ARG, "rank %d / root %d out of range for a world of %d", rank, root, world);
+    HIP_TRY(hipSetDevice(u->cfg.device_id));
+    int rc = upols_bcast_buffer(u);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (rank == root && (rc = upols_stage_root(u))) return rc;
+    if ((rc = adsp::rccl_broadcast_rank(unique_id, rank, world, root, u->cfg.device_id, u->d_spectra, kUpolsHdr + upols_spectra_floats(u), nullptr))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return upols_adopt(u, rank);
 }
 
 int adsp_upols_apply_host(adsp_upols* u, const void* in, void* out, int n_steps) {

@@ -50,6 +50,22 @@ _job_unique_ids = {}  # id file path -> the 128 bytes this process took part wit
 _ID_MAGIC = b"ADSPRCCL1"
 
 
+def forget_unique_ids():
+    """Drop the cached ids (engine.rccl_finalize calls this: the communicators built from them no longer exist) and remove the id
+    files this process wrote as rank 0."""
+    for path in list(_job_unique_ids):
+        _job_unique_ids.pop(path, None)
+        if path in _files_written:
+            _files_written.discard(path)
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+
+
+_files_written = set()
+
+
 def _id_file_path(path=None):
     """`path`, or $ADSP_RCCL_ID_FILE, or <tmp>/adsp_rccl_<MASTER_PORT>_<parent pid>_<run id>_<restart count>: ranks started by one
     torchrun agent share the parent pid and the port; the elastic run id and restart count (TORCHELASTIC_RUN_ID /
@@ -93,6 +109,7 @@ def exchange_unique_id(rank, world, make_id, path=None, timeout=120.0, max_age=3
         with os.fdopen(fd, "wb") as fh:
             fh.write(_ID_MAGIC + f"{os.getpid():010d}{time.time():020.3f}".encode() + uid)
         os.replace(tmp, path)
+        _files_written.add(path)
         import atexit
         atexit.register(lambda: os.path.exists(path) and os.remove(path))
     else:
@@ -154,11 +171,17 @@ class ShardedFirBank:
         self.rank, self.world = rank, world
         self.lo, self.hi = shard_range(total_channels, world, rank)
         self.total_channels = int(total_channels)
-        geo = overlap_save_geometry(fir, fft_mult, optimize_for)
         carrier = carrier or os.environ.get("ADSP_DIST_CARRIER") or ("torch" if pg or world == 1 else "abi")
         if carrier not in ("torch", "abi"):
             raise ValueError("carrier must be 'torch' or 'abi'")
         self.carrier = carrier
+        from .design import fits_one_transform
+        if not fits_one_transform(fir):
+            # a kernel longer than one transform (the reference's own GPU example: chunk 88200, Example4.py:5 / ModuleTestsGPU.py:35): the
+            # uniformly partitioned engine, whose filter is its partition spectra - the same ONE broadcast, of [partitions][block + 1] bins
+            self._init_long(fir, device, sample_format, engine_factory, pg)
+            return
+        geo = overlap_save_geometry(fir, fft_mult, optimize_for)
         kw = dict(**({'fft_mult': fft_mult} if fft_mult else {}), **({'sample_format': sample_format} if sample_format != "f32" else {}),
                   **({'optimize_for': optimize_for} if optimize_for != "stream" else {}))
         if carrier == "abi":
@@ -222,6 +245,56 @@ class ShardedFirBank:
             self.engine.upload_spectrum(self.spectrum, reach=max(0, -geo.shift))
 
 
+def _sharded_init_long(self, fir, device, sample_format, engine_factory, pg):
+    """ShardedFirBank for kernels longer than one transform: every rank builds its UpolsFirEngine (a rank without channels a one-channel
+    stand-in under the "abi" carrier - it still has to take part), rank 0's partition spectra reach the others through the carrier,
+    together with the tuple (chunk, block, partitions, delay) they belong to."""
+    from .design import PCM16_GAIN, choose_uniform_block, partition_uniform
+    from .engine import UpolsFirEngine, rccl_unique_id, upols_supported
+    if sample_format not in ("f32", "s16"):
+        raise ValueError("kernels longer than one transform: float32 or int16 samples")
+    if engine_factory is None and not upols_supported(fir):
+        raise ValueError("a sharded bank of kernels longer than one transform needs a chunk size that is a multiple of 4 and a delay of at least one block")
+    factory = engine_factory or UpolsFirEngine
+    # the block size is chosen for the JOB's channel count, so that every rank - whatever its shard - partitions alike
+    block = choose_uniform_block(fir, self.total_channels, UpolsFirEngine.block_sizes() if engine_factory is None else (8192, 16384))
+    kw = {"sample_format": sample_format} if sample_format != "f32" else {}
+    if self.carrier == "abi":
+        eng = factory(fir, channels=max(1, self.hi - self.lo), device=device, block=block, **kw)
+        eng.bcast_rank(exchange_unique_id(self.rank, self.world, rccl_unique_id), self.rank, self.world, 0)
+        self.spectrum, self.spectrum_tensor = eng.get_spectra(), None
+        if self.hi == self.lo:
+            eng.close()
+            eng = None
+        self.engine = eng
+        return
+    gain = PCM16_GAIN if sample_format == "s16" else 1.0
+    part = partition_uniform(fir, block, gain)
+    mine = np.array([fir.chunk_size, part.block, part.n_partitions, part.delay], dtype=np.float32)
+    spec = np.ascontiguousarray(part.spectra, dtype=np.float32).reshape(-1) if self.rank == 0 else np.zeros(part.spectra.size, np.float32)
+    bdev = None
+    try:
+        import torch
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_backend() == "nccl":
+            bdev = torch.device("cuda", device)
+    except ImportError:
+        pass
+    _, theirs = broadcast_spectrum(mine, 0, bdev)
+    if not np.array_equal(mine, theirs):
+        raise ValueError(f"rank {self.rank}: partitioning {mine.astype(int).tolist()} differs from rank 0's {theirs.astype(int).tolist()} - every rank "
+                         "must be constructed with the same kind of filter")
+    self.spectrum_tensor, self.spectrum = broadcast_spectrum(spec, 0, bdev)
+    if self.hi == self.lo:
+        self.engine = None
+        return
+    self.engine = factory(fir, channels=self.hi - self.lo, device=device, block=block, partition=part, **kw)
+    self.engine.set_spectra(self.spectrum)  # what the collective delivered (rank 0: its own design), bit-identical on every rank
+
+
+ShardedFirBank._init_long = _sharded_init_long
+
+
 class LocalFirBank:
     """All channels of a job on the GPUs of ONE process: contiguous channel shards, one engine per device, one host thread per
     device, and the filter shared by `adsp_bcast_spectrum` - the RCCL broadcast inside libadsp (ncclCommInitAll: no torchrun,
@@ -237,8 +310,16 @@ class LocalFirBank:
             from . import _capi
             devices = list(range(max(1, _capi.device_count())))
         if engine_factory is None:
-            from .engine import FirEngine, broadcast_filter
-            engine_factory, broadcast = FirEngine, (broadcast or broadcast_filter)
+            from .design import choose_uniform_block, fits_one_transform
+            from .engine import FirEngine, UpolsFirEngine, broadcast_filter, make_engine
+            broadcast = broadcast or broadcast_filter
+            if fits_one_transform(fir):
+                engine_factory = FirEngine
+            else:  # kernels longer than one transform shard too (Example4's chunk 88200): one block size for the whole job
+                job_block = choose_uniform_block(fir, int(total_channels), UpolsFirEngine.block_sizes())
+
+                def engine_factory(f, **kw):
+                    return make_engine(f, block=job_block, **kw)
         self.devices = [int(d) for d in devices]
         self.total_channels = int(total_channels)
         self.shards = [shard_range(total_channels, len(self.devices), i) for i in range(len(self.devices))]

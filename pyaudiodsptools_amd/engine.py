@@ -314,6 +314,13 @@ def broadcast_filter(engines, root=0):
     filter of engines[root] through an RCCL broadcast inside libadsp - no torch, no rendezvous."""
     lib = _capi.load()
     arr = (ctypes.c_void_p * len(engines))(*[e._h for e in engines])
+    if all(isinstance(e, UpolsFirEngine) for e in engines):  # kernels longer than one transform: adsp_upols_bcast_spectra
+        _capi.check(lib.adsp_upols_bcast_spectra(arr, len(engines), int(root)))
+        for e in engines:
+            e.fir = engines[root].fir
+        return
+    if any(isinstance(e, UpolsFirEngine) for e in engines):
+        raise ValueError("engines of different kinds cannot share a filter")
     _capi.check(lib.adsp_bcast_spectrum(arr, len(engines), int(root)))
     for e in engines:
         e.fir, e.spectrum = engines[root].fir, e.get_spectrum()  # each engine's own copy, as the collective left it
@@ -350,8 +357,12 @@ class ClockProbe:
 
 
 def rccl_finalize():
-    """adsp_rccl_finalize: destroy every RCCL communicator libadsp has built (no broadcast may be in flight)."""
+    """adsp_rccl_finalize: destroy every RCCL communicator libadsp has built (no broadcast may be in flight) - and forget the unique
+    ids this process took part with (dist.exchange_unique_id caches them per id file): a communicator is gone with its id, the next
+    broadcast of a job that re-forms draws a fresh one."""
     _capi.check(_capi.load().adsp_rccl_finalize())
+    from . import dist
+    dist.forget_unique_ids()
 
 
 def rccl_version():
@@ -428,10 +439,13 @@ class PartitionedFirEngine:
         self._lib = _capi.load()
 
     def set_epilogue(self, effect=None):
-        """The partial sums must be complete before a non-linear effect: it runs as one extra in-place elementwise pass."""
-        if effect is not None and effect.op == _capi.EFFECT_TREMOLO:
-            raise ValueError("the tremolo's per-channel time base is only available fused on a single-transform engine")
+        """The partial sums must be complete before a non-linear effect: it runs as one extra in-place elementwise pass.  A tremolo
+        starts its LFO at table index 0 here and advances with every chunk the engine filters, every channel in step."""
         self.epilogue = effect
+        if effect is not None and effect.op == _capi.EFFECT_TREMOLO:
+            import copy
+            self._lfo = copy.copy(effect)  # the engine's own LFO position (the effect object stays the caller's)
+            self._lfo.reset()
 
     def close(self):
         for e in self.engines:
@@ -440,18 +454,31 @@ class PartitionedFirEngine:
     def reset(self):
         for e in self.engines:
             e.reset()
+        if self.epilogue is not None and self.epilogue.op == _capi.EFFECT_TREMOLO:
+            self._lfo.reset()
+
+    def _run_epilogue(self, d_out, n_steps, stream):
+        p0, p1, p2 = (float(v) for v in self.epilogue.params())
+        if self.epilogue.op == _capi.EFFECT_TREMOLO:  # per step: all channels' chunks start at the same table index
+            base = d_out.data_ptr() if hasattr(d_out, "data_ptr") else int(d_out)
+            plane = self.channels * self.chunk_size * 4
+            for k in range(int(n_steps)):
+                phase = self._lfo._phase(self.chunk_size)
+                _capi.check(self._lib.adsp_tremolo_rows_device(self.device, p0, p1, int(p2), int(phase), _ptr(base + k * plane), _ptr(base + k * plane),
+                                                               self.channels, self.chunk_size, _ptr(stream)))
+            return
+        n = int(n_steps) * self.channels * self.chunk_size
+        _capi.check(self._lib.adsp_effect_device(self.device, self.epilogue.op, p0, p1, p2, 0, _ptr(d_out), _ptr(d_out), n, _ptr(stream)))
 
     def apply_device(self, d_in, d_out, n_steps=1, stream=None):
         for e in self.engines:  # stream-ordered: part 0 overwrites, the others add
             e.apply_device(d_in, d_out, n_steps, stream)
         if self.epilogue is not None:
-            p0, p1, p2 = (float(v) for v in self.epilogue.params())
-            n = int(n_steps) * self.channels * self.chunk_size
-            _capi.check(self._lib.adsp_effect_device(self.device, self.epilogue.op, p0, p1, p2, self.epilogue._phase(n),
-                                                     _ptr(d_out), _ptr(d_out), n, _ptr(stream)))
+            self._run_epilogue(d_out, n_steps, stream)
 
     def apply_host(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32)
+        squeeze = x.ndim == 2
         # host path: each part through its own staging buffers, summed in float64 and rounded once
         acc = None
         for e in self.engines:
@@ -461,7 +488,15 @@ class PartitionedFirEngine:
         for e in self.engines[1:]:
             e.set_accumulate(True)
         out = acc.astype(np.float32)
-        return out if self.epilogue is None else self.epilogue.apply(out, device=self.device)
+        if self.epilogue is None:
+            return out
+        if self.epilogue.op != _capi.EFFECT_TREMOLO:
+            return self.epilogue.apply(out, device=self.device)
+        import torch  # plumbing: a device copy of the batch for the row-wise pass
+        d = torch.from_numpy(out[None] if squeeze else out).cuda(self.device)
+        self._run_epilogue(d, d.shape[0], torch.cuda.current_stream(self.device).cuda_stream)
+        res = d.cpu().numpy()
+        return res[0] if squeeze else res
 
     def synchronize(self, stream=None):
         self.engines[0].synchronize(stream)
@@ -481,7 +516,9 @@ class UpolsFirEngine:
         sizes = (ctypes.c_int * 8)()
         return [int(v) for v in sizes[:lib.adsp_upols_block_sizes(sizes, 8)]]
 
-    def __init__(self, fir: FirStream, channels=1, device=0, sample_format="f32", max_steps=1, optimize_for="stream", block=None):
+    def __init__(self, fir: FirStream, channels=1, device=0, sample_format="f32", max_steps=1, optimize_for="stream", block=None,
+                 partition=None):
+        """`partition`: design.partition_uniform(fir, block, gain) computed by the caller (make_engine does, to test the preconditions)."""
         self._lib = _capi.load()
         self._h = ctypes.c_void_p(None)
         if sample_format not in ("f32", "s16"):
@@ -496,7 +533,9 @@ class UpolsFirEngine:
         if int(block) not in sizes:
             raise ValueError(f"block {block}: this build partitions into blocks of {sizes} samples")
         self.block = int(block)
-        self.partition = part = partition_uniform(fir, self.block, self.gain)
+        if partition is not None and (partition.block != self.block or self.gain != 1.0):
+            partition = None
+        self.partition = part = partition if partition is not None else partition_uniform(fir, self.block, self.gain)
         self.max_steps = int(max_steps)
         cfg = _capi.AdspUpolsConfig(self.device, self.chunk_size, self.channels, self.block, part.n_partitions, part.delay, self._fmt_code,
                                     self.max_steps)
@@ -522,10 +561,9 @@ class UpolsFirEngine:
         _capi.check(self._lib.adsp_upols_reset(self._h))
 
     def set_epilogue(self, effect=None):
-        """A stateless effect (effects.Effect; not the tremolo) applied to the output registers of the inverse transform."""
+        """An effect (effects.Effect) applied to the output registers of the inverse transform; a tremolo's LFO starts at table index 0
+        here and follows the stream (every channel in step, the reference's buffer quirk included)."""
         op, (p0, p1, p2) = (effect.op, effect.params()) if effect is not None else (_capi.EFFECT_NONE, (0.0, 0.0, 0.0))
-        if op == _capi.EFFECT_TREMOLO:
-            raise ValueError("the tremolo's per-channel time base is only available fused on a single-transform engine")
         _capi.check(self._lib.adsp_upols_set_epilogue(self._h, int(op), float(p0), float(p1), float(p2)))
         self.epilogue = effect
 
@@ -545,6 +583,33 @@ class UpolsFirEngine:
         out = np.empty_like(x)
         _capi.check(self._lib.adsp_upols_apply_host(self._h, _ptr(x), _ptr(out), x.shape[0]))
         return out[0] if squeeze else out
+
+    # -- the filter (dist.py: the path's one collective) ------------------------------------------------------------------------------
+    @property
+    def spectra_floats(self):
+        return self.partition.n_partitions * 2 * (self.block + 1)
+
+    def set_spectra(self, spectra_f32):
+        """Replace the filter by partition spectra of the same shape ([n_partitions][block + 1] interleaved float32), e.g. received by broadcast."""
+        sp = np.ascontiguousarray(spectra_f32, dtype=np.float32).reshape(-1)
+        if sp.size != self.spectra_floats:
+            raise ValueError(f"expected {self.spectra_floats} floats ({self.partition.n_partitions} partitions x {self.block + 1} bins), got {sp.size}")
+        _capi.check(self._lib.adsp_upols_set_spectra(self._h, _ptr(sp)))
+
+    def get_spectra(self):
+        """The interleaved float32 partition spectra the engine's tables were last built from (after a broadcast: what the collective left)."""
+        out = np.empty(self.spectra_floats, np.float32)
+        _capi.check(self._lib.adsp_upols_get_spectra(self._h, _ptr(out), out.size))
+        return out
+
+    get_spectrum = get_spectra  # (the name bench.py's checksum and dist.py use for every engine kind)
+
+    def bcast_rank(self, unique_id, rank, world, root=0):
+        """adsp_upols_bcast_spectra_rank: one process per GPU; afterwards every rank's engine runs the root's filter."""
+        uid = bytes(unique_id)
+        if len(uid) != _capi.ADSP_RCCL_UNIQUE_ID_BYTES:
+            raise ValueError(f"unique_id must be {_capi.ADSP_RCCL_UNIQUE_ID_BYTES} bytes")
+        _capi.check(self._lib.adsp_upols_bcast_spectra_rank(self._h, uid, int(rank), int(world), int(root)))
 
     def synchronize(self, stream=None):
         """Wait for everything the engine has launched (on `stream`, or wherever its last call went)."""
@@ -581,19 +646,79 @@ class MixBus:
             eng.apply_device(d_in, d_out, n_steps, stream)
 
 
+class Pcm16Adapter:
+    """int16 PCM batches through a float32 engine whose kernels cannot take them directly - chunk sizes that are not multiples of 4 (the
+    dword-access kernels are float32 only), kernels longer than one transform on such chunk sizes.  The arithmetic is the int16 engines':
+    (float)x in, (int16)trunc(y) out with the reference's /32768 and *32767 folded into the taps (Utility.py:236-237, :306 -
+    design.PCM16_GAIN); only the two conversions run as passes of their own (numpy on the host path, torch - plumbing - on the device path)."""
+
+    def __init__(self, fir: FirStream, **kw):
+        self.fir = fir
+        scaled = FirStream(np.asarray(fir.taps, dtype=np.float64) * PCM16_GAIN, fir.chunk_size, fir.latency_chunks, fir.lookahead)
+        self.inner = make_engine(scaled, **kw)
+        self.channels, self.chunk_size, self.device = self.inner.channels, self.inner.chunk_size, self.inner.device
+        self.sample_format, self.dtype, self.gain = "s16", np.int16, PCM16_GAIN
+
+    def close(self):
+        self.inner.close()
+
+    def reset(self):
+        self.inner.reset()
+
+    def synchronize(self, stream=None):
+        self.inner.synchronize(stream)
+
+    def apply_host(self, x):
+        if np.asarray(x).dtype != np.int16:
+            raise TypeError("this engine filters int16 PCM; pass an int16 array")
+        y = self.inner.apply_host(np.asarray(x).astype(np.float32))
+        return np.trunc(y).astype(np.int32).astype(np.int16)  # truncation toward zero, low 16 bits kept: (x * 32767).astype('int16')
+
+    def apply_device(self, d_in, d_out, n_steps=1, stream=None):
+        """d_in / d_out: int16 torch tensors [n_steps, C, N] on the engine's GPU (raw addresses cannot be converted here)."""
+        import torch
+        if not (hasattr(d_in, "dtype") and d_in.dtype == torch.int16 and d_out.dtype == torch.int16):
+            raise TypeError("the int16 adapter's device path takes torch.int16 tensors")
+        ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream)) if isinstance(stream, int) and stream else torch.cuda.stream(torch.cuda.current_stream(d_in.device))
+        with ctx:
+            xf = d_in.to(torch.float32)
+            yf = torch.empty_like(xf)
+            self.inner.apply_device(xf, yf, n_steps, torch.cuda.current_stream(d_in.device).cuda_stream)
+            d_out.copy_(torch.trunc(yf).to(torch.int32).to(torch.int16))
+
+
 def make_engine(fir: FirStream, **kw):
     """FirEngine when the kernel fits one transform; otherwise the uniformly partitioned engine (UpolsFirEngine: one forward transform
     per input block, a frequency-domain delay line, one inverse per output block), and where its conditions do not hold (chunk sizes
-    that are not multiples of 4, streams delayed by less than a block) PartitionedFirEngine (one engine pass per kernel slice)."""
+    that are not multiples of 4, streams delayed by less than a block) PartitionedFirEngine (one engine pass per kernel slice).
+    Keyword arguments an engine kind does not take (ring_slots / fft_mult beyond FirEngine, max_taps beyond PartitionedFirEngine) are
+    dropped for the others."""
+    n = int(fir.chunk_size)
+    if kw.get("sample_format", "f32") == "s16" and (n % 4 != 0 or n < 16):
+        # int16 PCM on a chunk size the 8-byte int16 accesses cannot tile: the float32 dword-access kernels behind two conversion passes
+        return Pcm16Adapter(fir, **{k: v for k, v in kw.items() if k != "sample_format"})
     if fits_one_transform(fir):
+        kw.pop("max_taps", None)
+        kw.pop("max_steps", None)
+        kw.pop("block", None)
         return FirEngine(fir, **kw)
     kw.pop("ring_slots", None)
     kw.pop("fft_mult", None)
-    try:
-        partition_uniform(fir, _capi.load().adsp_upols_block_size())
-    except ValueError:
-        if kw.get("sample_format", "f32") != "f32":
-            raise ValueError("kernels longer than one transform with a chunk size that is not a multiple of 4 are supported for float32 samples only")
-        kw.pop("sample_format", None)
-        return PartitionedFirEngine(fir, **kw)
-    return UpolsFirEngine(fir, **kw)
+    max_taps = kw.pop("max_taps", None)
+    if upols_supported(fir):  # (the cheap preconditions: the partitions themselves - an rfft of the whole kernel - are computed once, by the engine)
+        return UpolsFirEngine(fir, **kw)
+    if kw.get("sample_format", "f32") != "f32":
+        raise ValueError("kernels longer than one transform whose stream is delayed by less than a block are supported for float32 samples only")
+    for k in ("sample_format", "max_steps", "block"):
+        kw.pop(k, None)
+    if max_taps is not None:
+        kw["max_taps"] = max_taps
+    return PartitionedFirEngine(fir, **kw)
+
+
+def upols_supported(fir: FirStream, block=None):
+    """The preconditions of the uniformly partitioned engine (adsp_upols_create), without designing anything: a chunk size that is a
+    multiple of 4 (>= 16) and a stream delayed by at least one block."""
+    block = int(block or _capi.load().adsp_upols_block_size())
+    n = int(fir.chunk_size)
+    return n % 4 == 0 and n >= 16 and int(fir.delay) - (int(fir.delay) % 4) >= block

@@ -18,7 +18,7 @@ import numpy as np
 
 from . import config
 from .design import FirStream
-from .engine import ExactFirEngine, FirEngine
+from .engine import ExactFirEngine, FirEngine, make_engine
 
 
 # ---- the reference's chunk plumbing ---------------------------------------------------------
@@ -92,6 +92,39 @@ def _write_pcm16(path, int_data, n_channels, rate):
 
 
 # ---- many files, one launch -------------------------------------------------------------------
+# Engines of earlier process() calls, kept for the next one with the same filter, channel count and mode: creating an engine (tables,
+# ring, plan set-up: ~10 ms, more than filtering a few hundred files) used to dominate WavBank.process.  A reused engine starts from
+# zero history like a fresh one (reset).  At most _BANK_ENGINES live at a time, oldest closed first.
+_BANK_ENGINES = 4
+_bank_cache = {}
+
+
+def _bank_engine(fir, channels, device, exact):
+    import hashlib
+    taps = np.ascontiguousarray(fir.taps, dtype=np.float64)
+    key = (hashlib.blake2b(taps.tobytes(), digest_size=16).hexdigest(), len(taps), int(fir.chunk_size), int(fir.latency_chunks), int(fir.lookahead),
+           int(channels), int(device), str(exact))
+    eng = _bank_cache.pop(key, None)
+    if eng is not None:
+        eng.reset()
+    elif exact == "fft":
+        eng = FirEngine(fir, channels=channels, device=device, sample_format="s16_f64", optimize_for="batch")
+    elif exact:
+        eng = ExactFirEngine(fir, channels=channels, device=device, sample_format="s16")
+    else:  # (make_engine: kernels longer than one transform - chunk 88200 - and chunk sizes that are not multiples of 4 go the same way)
+        eng = make_engine(fir, channels=channels, device=device, sample_format="s16", optimize_for="batch")
+    _bank_cache[key] = eng  # most recently used last
+    while len(_bank_cache) > _BANK_ENGINES:
+        _bank_cache.pop(next(iter(_bank_cache))).close()
+    return eng
+
+
+def close_bank_engines():
+    """Release the engines WavBank.process keeps between calls."""
+    while _bank_cache:
+        _bank_cache.pop(next(iter(_bank_cache))).close()
+
+
 class WavBank:
     """A bank of 16-bit WAV files filtered together.
 
@@ -127,14 +160,8 @@ class WavBank:
         reference's int16 stream bit for bit (O(taps) per sample - fine for files); exact="fft": the FFT engine in FLOAT64
         (sample_format "s16_f64") - the direct sum's int16 stream except where the float64 result lies within ~1e-15 of a
         float32 rounding boundary (about one sample in ten million), at a third of the float32 engine's rate."""
-        if exact == "fft":
-            eng = FirEngine(fir, channels=self.channels, device=device, sample_format="s16_f64", optimize_for="batch")
-        elif exact:
-            eng = ExactFirEngine(fir, channels=self.channels, device=device, sample_format="s16")
-        else:
-            eng = FirEngine(fir, channels=self.channels, device=device, sample_format="s16", optimize_for="batch")
+        eng = _bank_engine(fir, self.channels, device, exact)
         out = eng.apply_host(self.batch())  # [steps, C, N] int16
-        eng.close()
         flat = out.transpose(1, 0, 2).reshape(self.channels, -1)
         result, c0 = [], 0
         for _, n_ch, _, _ in self.files:

@@ -257,3 +257,80 @@ def test_local_bank_float64_engines_keep_their_filter_through_the_broadcast():
     bank.close()
     sb = dist.ShardedFirBank(fir, 4, engine_factory=Eng, sample_format="s16_f64", carrier="torch")
     assert sb.engine.uploads == 0 and sb.engine.kw == {"sample_format": "s16_f64"}
+
+
+# ---- kernels longer than one transform shard too (round 6): ShardedFirBank -> the uniformly partitioned engine, its partition spectra
+# are what the one broadcast carries -----------------------------------------------------------------------------------------------
+class NumpyUpolsEngine:
+    """Stand-in for UpolsFirEngine: tests/test_upols_host.py's numpy mirror of the engine's block bookkeeping per channel, the partition
+    spectra supplied from outside (set_spectra: what the broadcast delivered)."""
+
+    def __init__(self, fir, channels=1, device=0, block=8192, partition=None, **kw):
+        from test_upols_host import UpolsMirror
+        self.mirrors = [UpolsMirror(fir, block, 1) for _ in range(channels)]
+        self.block, self.n = block, fir.chunk_size
+
+    def set_spectra(self, spectra_f32):
+        sp = np.asarray(spectra_f32, np.float32).reshape(-1, self.block + 1, 2)
+        for m in self.mirrors:
+            assert sp.shape[0] == m.P
+            m.H = sp[..., 0].astype(np.float64) + 1j * sp[..., 1].astype(np.float64)
+
+    def apply_host(self, x):  # [C, N]
+        return np.stack([m.apply(x[c]) for c, m in enumerate(self.mirrors)]).astype(np.float32)
+
+
+def _long_worker(rank, world, port, total_channels, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from pyaudiodsptools_amd import design
+    from pyaudiodsptools_amd.dist import ShardedFirBank, init_process_group
+    init_process_group("gloo")
+    n, steps, taps_len = 20000, 3, 40001
+    rng = np.random.default_rng(5 if rank == 0 else 6)   # only rank 0 holds the real kernel
+    taps = rng.standard_normal(taps_len) * np.hanning(taps_len) / taps_len ** 0.5
+    fir = design.FirStream(taps, n, latency_chunks=2, lookahead=20000)
+    bank = ShardedFirBank(fir, total_channels, device=0, engine_factory=NumpyUpolsEngine)
+    x = np.random.default_rng(98).uniform(-1, 1, (steps, total_channels, n)).astype(np.float32)
+    mine = x[:, bank.lo:bank.hi]
+    y = np.zeros((steps, 0, n), np.float32) if bank.engine is None else np.stack([bank.engine.apply_host(mine[k]) for k in range(steps)])
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), lo=bank.lo, hi=bank.hi, y=y, spec=bank.spectrum)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total_channels", [1, 3])
+def test_two_rank_sharded_long_kernel_matches_the_direct_convolution(tmp_path, total_channels):
+    import torch.multiprocessing as mp
+    from oracle import fftfilter_oracle as orc
+    world = 2
+    mp.spawn(_long_worker, args=(world, _free_port(), total_channels, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    assert int(parts[0]["lo"]) == 0 and int(parts[-1]["hi"]) == total_channels and int(parts[0]["hi"]) == int(parts[1]["lo"])
+    assert np.array_equal(parts[0]["spec"], parts[1]["spec"]) and parts[0]["spec"].size == 5 * 2 * 8193  # 40001 taps: 5 partitions of 8192
+    y = np.concatenate([p["y"] for p in parts], axis=1)
+    n, steps, taps_len = 20000, 3, 40001
+    taps = np.random.default_rng(5).standard_normal(taps_len) * np.hanning(taps_len) / taps_len ** 0.5
+    x = np.random.default_rng(98).uniform(-1, 1, (steps, total_channels, n)).astype(np.float32)
+    for c in range(total_channels):
+        want = orc.direct_stream_convolution(taps, x[:, c].reshape(-1), n, 2, 20000)
+        assert_parity(y[:, c].reshape(-1), want, what=f"channel {c}")
+
+
+def test_finalize_forgets_the_unique_ids(tmp_path, monkeypatch):
+    """rccl_finalize destroys the communicators, so the ids cached per id file must go with them."""
+    from pyaudiodsptools_amd import dist
+    path = str(tmp_path / "id")
+    calls = []
+
+    def make_id():
+        calls.append(1)
+        return bytes([len(calls)]) * 128
+    a = dist.exchange_unique_id(0, 1, make_id, path=path)
+    assert dist.exchange_unique_id(0, 1, make_id, path=path) == a and len(calls) == 1   # cached
+    dist.forget_unique_ids()
+    b = dist.exchange_unique_id(0, 1, make_id, path=path)
+    assert b != a and len(calls) == 2
+    dist.forget_unique_ids()
