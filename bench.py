@@ -939,10 +939,10 @@ def compact_line(line, notes=None, path=""):
         return out
     if isinstance(line, list):
         return [compact_line(v, notes, f"{path}[{i}]") for i, v in enumerate(line)]
-    if isinstance(line, str) and len(line) > 140 and path.count("/") > 1:
+    if isinstance(line, str) and len(line) > 200 and path.count("/") > 1:
         if notes is not None:
             notes[path] = line
-        return line[:137] + "..."
+        return line[:197] + "..."
     return line
 
 
@@ -1235,9 +1235,8 @@ def main():
                 x_orc = (x_par or {}).get("oracle")
                 extra_configs[key] = {"value": round(rx.samples_per_step * world * x_steps / x_wall / 1e6, 1), "unit": "Msamples/s", "n_gpus": world,
                                       "steps": x_steps, "warmup": 2, "runs": 3, "ms_per_step": round(x_wall * 1e3 / x_steps, 4),
-                                      "workload": f"{FILTER_NAMES[ax.filter]} @ {ax.fs} Hz, {ax.channels} channels x {ax.chunk}-sample chunks per GPU, "
-                                                  f"{rx.cps} chunks per step, {rx.eng.block_outputs} of {rx.eng.geometry.fft_size} samples kept per transform, "
-                                                  f"{len(rx.eng.fir.taps)} taps",
+                                      "workload": f"{FILTER_NAMES[ax.filter]} @ {ax.fs} Hz, {ax.channels} ch x {ax.chunk} per GPU, {rx.cps} chunks per step, "
+                                                  f"{rx.eng.block_outputs} of {rx.eng.geometry.fft_size} kept per transform, {len(rx.eng.fir.taps)} taps",
                                       "roofline": {"bound": "hbm", "achieved": round(x_alg / per / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                    "frac": round(x_alg / per / 1e9 / HBM_PEAK_GBS, 4), "traffic": x_traffic, "traffic_source": x_src,
                                                    "kernel": "adsp::fftconv_kernel", "avg_launch_us": round(per * 1e6, 2), "launches": x_launches,

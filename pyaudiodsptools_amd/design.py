@@ -285,14 +285,16 @@ def choose_uniform_block(fir: "FirStream", channels: int, sizes=(8192, 16384)) -
     """Block size of a uniformly partitioned engine.  Per output sample the multiply launch reads taps / B x 16 bytes of tables and
     8 of spectra, so a larger block pays for kernels of many partitions - where the stream's delay allows it (partition_uniform:
     delay >= block) and a call has blocks enough to fill the chip several times over; more and shorter workgroups win everywhere
-    else.  Measured at chunk 88200 (profiles/r5_upols_compact_tables.txt, r5_upols_block_16384.txt, r5_upols_block_threshold.txt): the
-    EQ composite (11 partitions of 8192) at 1024 channels -3 % on blocks of 16384, the low cut (6 partitions) +5 %, 64 channels +19 %."""
+    else.  Measured at chunk 88200, round 6 (rotated partition order, tail-only ring update: profiles/r6_upols_block_sizes.txt): at 1024
+    channels blocks of 16384 take the EQ composite (11 partitions of 8192) from 1250 to 1045 us per call and the low cut (6 partitions)
+    from 879 to 818; at 64 channels 76.0 -> 76.3 and 59.6 -> 63.8.  (Round 5, before those two changes, had the low cut 5 % slower on the
+    large block: profiles/r5_upols_block_16384.txt.)"""
     delay = int(fir.delay) - int(fir.delay) % 4
     valid = sorted(b for b in sizes if b <= delay)
     if not valid:
         return min(sizes)  # (partition_uniform raises for it)
     small, big = valid[0], valid[-1]
-    many_partitions = -(-(len(fir.taps) + int(fir.delay) % 4) // small) >= 10
+    many_partitions = -(-(len(fir.taps) + int(fir.delay) % 4) // small) >= 4
     return big if many_partitions and int(channels) * int(fir.chunk_size) >= 1024 * big else small
 
 

@@ -118,9 +118,11 @@ def test_upols_engine_int16_and_fused_effect(adsp, block):
     torch.cuda.synchronize()
     t = _exact(adsp, eng.fir, x).cpu().numpy()
     assert_parity(y.cpu().numpy(), fx.saturator(t), what="fused saturator")
-    adsp.config.initialize(44100, n)
-    with pytest.raises(ValueError):
-        eng.set_epilogue(adsp.CreateTremolo())
+    # (round 6: the tremolo fuses too - tests/test_gpu_round6.py::test_tremolo_behind_a_long_kernel; an int16 engine still takes no effect)
+    eng.close()
+    eng = adsp.UpolsFirEngine(fir, channels=2, sample_format="s16", block=block)
+    with pytest.raises(adsp.AdspError):
+        eng.set_epilogue(adsp.CreateSaturator())
     eng.close()
 
 
@@ -139,7 +141,8 @@ def test_upols_raw_abi_refusals(adsp):
         assert lib.adsp_last_error()
     cfg = _capi.AdspUpolsConfig(**ok)
     assert lib.adsp_upols_create(ctypes.byref(cfg), spec.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)) == 0
-    assert lib.adsp_upols_apply_device(h, None, None, 1, None) != 0 and lib.adsp_upols_set_epilogue(h, 5, 0.4, 1e-4, 100.0) != 0
+    assert lib.adsp_upols_apply_device(h, None, None, 1, None) != 0 and lib.adsp_upols_set_epilogue(h, 5, 0.4, 1e-4, 0.0) != 0  # tremolo: table length 0
+    assert lib.adsp_upols_set_epilogue(h, 7, 0.0, 0.0, 0.0) != 0 and lib.adsp_upols_set_epilogue(h, 5, 0.4, 1e-4, 100.0) == 0 and lib.adsp_upols_set_epilogue(h, 0, 0.0, 0.0, 0.0) == 0
     import torch
     buf = torch.zeros((3, 2, 40000), device="cuda")   # in place, or overlapping by one chunk: refused
     assert lib.adsp_upols_apply_device(h, ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(buf.data_ptr()), 2, None) != 0 and b"overlap" in lib.adsp_last_error()
