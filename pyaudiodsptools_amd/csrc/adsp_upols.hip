@@ -153,7 +153,7 @@ __device__ __forceinline__ bool upols_block(const UpolsArgs& a, int& c, int& blk
 
 // ---- launch 1: window -> forward passes -> delay line ----------------------------------------------------------------
 template <class PL, bool S16>
-__global__ __launch_bounds__(PL::T, PL::P > 32 ? 2 : 3) void upols_forward_kernel(const UpolsArgs a) {
+__global__ __launch_bounds__(PL::T, PL::P > 32 ? 2 : (PL::T > 256 ? 4 : 3)) void upols_forward_kernel(const UpolsArgs a) {
     constexpr int P = PL::P, T = PL::T;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     real2* lds = reinterpret_cast<real2*>(smem_raw);
@@ -521,8 +521,13 @@ UpolsPlan upols_plan() {
     return p;
 }
 
+// B = 16384 as 32 points per thread in 512 threads (radices 32 x 32 x 16, half-buffer exchange): 64 accumulators instead of 128 leave the
+// multiply launch room for four stages of requests instead of two - twice the bytes in flight per wave at half the bytes per output sample
+#ifndef ADSP_UPOLS_PLAN_16384
+#define ADSP_UPOLS_PLAN_16384 ADSP_PLAN_16384
+#endif
 const UpolsPlan* upols_plans(int* count) {
-    static const UpolsPlan plans[] = {upols_plan<ADSP_PLAN_8192>(), upols_plan<ADSP_PLAN_16384>()};
+    static const UpolsPlan plans[] = {upols_plan<ADSP_PLAN_8192>(), upols_plan<ADSP_UPOLS_PLAN_16384>()};
     if (count) *count = (int)(sizeof plans / sizeof plans[0]);
     return plans;
 }
