@@ -755,8 +755,9 @@ def long_kernel_figures(dev, channels=64, calls=24):
         ex.close()
         del t
         t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < 0.1:  # clock ramp
-            eng.apply_device(x[0], y[0], 1, s)
+        while time.perf_counter() - t_pre < 0.3:  # clock ramp: back-to-back calls (a synchronisation per call leaves the GPU idle half of the time)
+            for k in range(8):
+                eng.apply_device(x[k % 4], y[k % 4], 1, s)
             torch.cuda.synchronize(dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         runs = []
@@ -869,11 +870,16 @@ def host_batch_figures(dev, gib=1.0, files=256, seconds_per_file=10):
         res["wavbank_process"] = {"files": files, "seconds_of_audio_per_file": seconds_per_file, "pcm_gib": round(pcm_bytes / 2 ** 30, 3),
                                   "read_and_pack_seconds": round(t_read, 3), "process_seconds": round(t_proc, 4),
                                   "gb_per_s_each_direction": round(pcm_bytes / t_proc / 1e9, 2), "msamples_s": round(pcm_bytes / 2 / t_proc / 1e6, 1),
-                                  "note": "WavBank.process(fir): batch() transposition + engine creation + apply_host (int16, 4 bytes per sample over the "
-                                          "link) + per-file views; file reading is not part of process()"}
+                                  "note": "WavBank.process(fir): batch() transposition + apply_host on the engine the bank kept from its first call (int16, "
+                                          "4 bytes per sample over the link) + per-file views; file reading is not part of process()"}
     finally:
         import shutil
         shutil.rmtree(tmp, ignore_errors=True)
+        try:
+            from pyaudiodsptools_amd import wavio
+            wavio.close_bank_engines()
+        except Exception:
+            pass
     return res
 
 

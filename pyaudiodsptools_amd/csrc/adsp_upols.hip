@@ -55,6 +55,9 @@ int rccl_broadcast_rank(const char* unique_id, int rank, int world, int root, in
 #ifndef ADSP_UPOLS_MAC_WAVES
 #define ADSP_UPOLS_MAC_WAVES 2
 #endif
+#ifndef ADSP_UPOLS_FWD_NT
+#define ADSP_UPOLS_FWD_NT 0
+#endif
 #ifndef ADSP_UPOLS_ABLATE  // tuning builds only (make tuning EXTRA=-DADSP_UPOLS_ABLATE=<mask>): 1 no table loads, 2 no spectrum loads, 4 table entries (c1, c2, c4) not formed
 #define ADSP_UPOLS_ABLATE 0
 #endif
@@ -193,8 +196,11 @@ __global__ __launch_bounds__(PL::T, PL::P > 32 ? 2 : (PL::T > 256 ? 4 : 3)) void
             }
             off += chan_units;
         }
+        // every sample of a window is read by TWO workgroups (the blocks before and after share a half each): plain loads, so that
+        // the neighbour's request is an L2 hit (ADSP_UPOLS_FWD_NT=1: the non-temporal loads of round 5, profiles/r6_upols_forward_loads.txt)
         if constexpr (S16) raw[u] = *reinterpret_cast<const v2u*>(base + off);
-        else raw[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(base + off));
+        else if constexpr (ADSP_UPOLS_FWD_NT) raw[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(base + off));
+        else raw[u] = *reinterpret_cast<const v4f*>(base + off);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

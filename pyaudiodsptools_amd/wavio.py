@@ -119,6 +119,19 @@ def _bank_engine(fir, channels, device, exact):
     return eng
 
 
+def _over_channel_groups(channels, work, threads=8):
+    """work(a, b) for disjoint channel ranges on a few threads (numpy releases the GIL inside large copies)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    n = max(1, min(threads, os.cpu_count() or 1, channels))
+    if n == 1:
+        work(0, channels)
+        return
+    bounds = [channels * i // n for i in range(n + 1)]
+    with ThreadPoolExecutor(max_workers=n) as pool:
+        list(pool.map(lambda i: work(bounds[i], bounds[i + 1]), range(n)))
+
+
 def close_bank_engines():
     """Release the engines WavBank.process keeps between calls."""
     while _bank_cache:
@@ -151,8 +164,13 @@ class WavBank:
         self.channels = len(chans)
 
     def batch(self):
-        """[steps, channels, chunk] int16, the engine's batch layout."""
-        return np.ascontiguousarray(self.pcm.reshape(self.channels, self.steps, self.chunk_size).transpose(1, 0, 2))
+        """[steps, channels, chunk] int16, the engine's batch layout - built once per bank (the files do not change) by a few threads:
+        a single-threaded numpy transposition of a few hundred megabytes took as long as the whole rest of process()."""
+        if getattr(self, "_batch", None) is None:
+            self._batch = np.empty((self.steps, self.channels, self.chunk_size), np.int16)
+            src = self.pcm.reshape(self.channels, self.steps, self.chunk_size)
+            _over_channel_groups(self.channels, lambda a, b: self._batch[:, a:b].__setitem__(slice(None), src[a:b].transpose(1, 0, 2)))
+        return self._batch
 
     def process(self, fir: FirStream, device=0, exact=False):
         """exact=False: the int16 FFT engine in float32 (within one LSB of the reference's WAV output, a few samples per ten
@@ -162,7 +180,9 @@ class WavBank:
         float32 rounding boundary (about one sample in ten million), at a third of the float32 engine's rate."""
         eng = _bank_engine(fir, self.channels, device, exact)
         out = eng.apply_host(self.batch())  # [steps, C, N] int16
-        flat = out.transpose(1, 0, 2).reshape(self.channels, -1)
+        flat = np.empty((self.channels, self.steps * self.chunk_size), np.int16)
+        dst = flat.reshape(self.channels, self.steps, self.chunk_size)
+        _over_channel_groups(self.channels, lambda a, b: dst[a:b].__setitem__(slice(None), out[:, a:b].transpose(1, 0, 2)))
         result, c0 = [], 0
         for _, n_ch, _, _ in self.files:
             result.append(flat[c0] if n_ch == 1 else flat[c0:c0 + n_ch].T)
