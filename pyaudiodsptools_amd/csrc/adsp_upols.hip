@@ -232,8 +232,14 @@ __global__ __launch_bounds__(PL::T, PL::P > 32 ? 2 : (PL::T > 256 ? 4 : 3)) void
 #pragma unroll
     for (int h = 0; h < RR / 2; ++h) {
         const int a0 = NB * (2 * h), a1 = NB * (2 * h + 1), b0 = NB * (RR - 1 - 2 * h) + 1, b1 = NB * (RR - 2 - 2 * h) + 1;
+#if defined(ADSP_TUNING_BUILD) && defined(ADSP_UPOLS_Z_NT_STORE)  // tuning A/B: non-temporal stores of the spectrum (profiles/r6_upols_policies.txt)
+        typedef float v4f_z __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(v4f_z{xr[a0], xi[a0], xr[a1], xi[a1]}, reinterpret_cast<v4f_z*>(z + static_cast<size_t>(2 * h) * T));
+        __builtin_nontemporal_store(v4f_z{xr[b0], xi[b0], xr[b1], xi[b1]}, reinterpret_cast<v4f_z*>(z + static_cast<size_t>(2 * h + 1) * T));
+#else
         z[static_cast<size_t>(2 * h) * T] = make_float4(xr[a0], xi[a0], xr[a1], xi[a1]);
         z[static_cast<size_t>(2 * h + 1) * T] = make_float4(xr[b0], xi[b0], xr[b1], xi[b1]);
+#endif
     }
 }
 

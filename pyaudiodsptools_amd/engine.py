@@ -348,12 +348,11 @@ class ClockProbe:
         self._res = ctypes.c_void_p(None)
         return mhz.value
 
-    def __del__(self):  # a probe nobody read: its pinned result buffer is freed by the read (which waits for the probe kernel)
-        try:
-            if getattr(self, "_res", None) is not None and self._res.value:
-                self.read()
-        except Exception:
-            pass
+    def __del__(self):
+        # A probe nobody read keeps its 16 bytes of pinned result memory: freeing it means waiting for the probe kernel (and for whatever
+        # is queued in front of it on its stream), and a destructor - run by the garbage collector at an arbitrary point - must not block
+        # on the GPU.  bench.py reads every probe it launches.
+        self._res = None
 
 
 def rccl_finalize():
