@@ -1295,7 +1295,9 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "adsp::fftconv_kernel", "avg_launch_us": round(per_launch_s * 1e6, 2),
                          "launches": launches, "algorithmic_bytes_per_launch": int(alg_bytes * samples_per_launch),
-                         "traffic_source": traffic_src},
+                         "traffic_source": traffic_src,
+                         # the shader clock the power manager granted the median run (the kernel is clock-limited: profiles/r5_sol_model.md)
+                         "shader_mhz": None if runs[med][3] is None else round(runs[med][3], 1)},
         }
         line["runs"] = runs_block
         line["parity_checked"] = parity is not None
