@@ -85,7 +85,7 @@ class _FFTDevice:
 
     def _nonfinite(self, x32):
         """True when the float32 vector holds a NaN / Inf: x . 0 is NaN exactly then (finite * 0 = 0, Inf * 0 = NaN * 0 = NaN) - one
-        BLAS dot instead of an elementwise pass (0.3 against 2.5 microseconds at N = 4096)."""
+        BLAS dot (about a microsecond at N = 4096) instead of an elementwise pass and a reduction."""
         return bool(np.isnan(np.dot(x32, self._zeros32)))
 
     def apply(self, float32_array_input):
