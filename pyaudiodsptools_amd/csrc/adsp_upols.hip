@@ -203,20 +203,28 @@ __global__ __launch_bounds__(PL::T, PL::P > 32 ? 2 : (PL::T > 256 ? 4 : 3)) void
         else raw[u] = *reinterpret_cast<const v4f*>(base + off);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S16) {
 #pragma unroll
-    for (int u = 0; u < P / 2; ++u) {
-        if constexpr (S16) {
+        for (int u = 0; u < P / 2; ++u) {
             const v2u v = raw[u];
             const unsigned sx = lane_xor1_u(odd ? v.x : v.y);
             unpack_s16(odd ? sx : v.x, xr[2 * u], xi[2 * u]);
             unpack_s16(odd ? v.y : sx, xr[2 * u + 1], xi[2 * u + 1]);
-        } else {
-            const v4f v = raw[u];
-            const float sx = lane_xor1(odd ? v.x : v.z), sy = lane_xor1(odd ? v.y : v.w);
-            xr[2 * u] = odd ? sx : v.x;
-            xi[2 * u] = odd ? sy : v.y;
-            xr[2 * u + 1] = odd ? v.z : sx;
-            xi[2 * u + 1] = odd ? v.w : sy;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < P / 2; u += 2) {  // two register pairs per exchange (fftconv_core.inc: lane_pair_exchange4)
+            const float ea[4] = {raw[u].x, raw[u].y, raw[u + 1].x, raw[u + 1].y}, eb[4] = {raw[u].z, raw[u].w, raw[u + 1].z, raw[u + 1].w};
+            float an[4], bn[4];
+            lane_pair_exchange4<(ADSP_DPP_SELECT & 1) && P < 64>(ea, eb, an, bn, odd);
+            xr[2 * u] = an[0];
+            xi[2 * u] = an[1];
+            xr[2 * u + 1] = bn[0];
+            xi[2 * u + 1] = bn[1];
+            xr[2 * u + 2] = an[2];
+            xi[2 * u + 2] = an[3];
+            xr[2 * u + 3] = bn[2];
+            xi[2 * u + 3] = bn[3];
         }
     }
     int ja, jb;
@@ -471,19 +479,20 @@ __global__ __launch_bounds__(PL::T, ADSP_UPOLS_MAC_WAVES) void upols_mac_kernel(
     const bool odd = tid & 1;
     const int total = a.n_steps * N;
     const int o = a.rel_first + blk * PL::M - PL::M;  // output time of circular index 0 of this block
+    float ea[4] = {0.f, 0.f, 0.f, 0.f}, eb[4] = {0.f, 0.f, 0.f, 0.f};  // (float32: the lane pairs' 16 bytes of two register pairs, lane_pair_exchange4)
+    static_assert((P / 4) % 2 == 0, "register pairs are exchanged two at a time");
 #pragma unroll
     for (int u = P / 4; u < P / 2; ++u) {
         const int elem = (tid - (odd ? 1 : 0)) + T * (2 * u + (odd ? 1 : 0));
         const int tau = o + 2 * elem;
-        float sx, sy;
         unsigned w0 = 0, w1 = 0, swx = 0;
         if constexpr (S16) {
             w0 = pack_s16(ar[2 * u], ai[2 * u]);
             w1 = pack_s16(ar[2 * u + 1], ai[2 * u + 1]);
             swx = lane_xor1_u(odd ? w0 : w1);
-        } else {
-            sx = lane_xor1(odd ? ar[2 * u] : ar[2 * u + 1]);
-            sy = lane_xor1(odd ? ai[2 * u] : ai[2 * u + 1]);
+        } else if ((u & 1) == 0) {
+            const float xa[4] = {ar[2 * u], ai[2 * u], ar[2 * u + 2], ai[2 * u + 2]}, xb[4] = {ar[2 * u + 1], ai[2 * u + 1], ar[2 * u + 3], ai[2 * u + 3]};
+            lane_pair_exchange4<(ADSP_DPP_SELECT & 2) && P < 64>(xa, xb, ea, eb, odd);
         }
         if (tau >= 0 && tau < total) {  // (the ends of a call cut a block: multiples of 4 samples on both sides)
             int k, r;
@@ -495,7 +504,7 @@ __global__ __launch_bounds__(PL::T, ADSP_UPOLS_MAC_WAVES) void upols_mac_kernel(
                 __builtin_nontemporal_store(v, reinterpret_cast<v2u*>(dst));
             } else {
                 typedef float v4f __attribute__((ext_vector_type(4)));
-                const v4f v = odd ? v4f{sx, sy, ar[2 * u + 1], ai[2 * u + 1]} : v4f{ar[2 * u], ai[2 * u], sx, sy};
+                const v4f v = v4f{ea[2 * (u & 1)], ea[2 * (u & 1) + 1], eb[2 * (u & 1)], eb[2 * (u & 1) + 1]};
                 __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(dst));
             }
         }

@@ -1,11 +1,35 @@
 #!/bin/bash
-# round-6 GPU session 9: two more one-line policies of the long-kernel engine against the tree (all tuning builds of the same source):
-# the multiply launch at three workgroups per CU (168 VGPRs) and non-temporal stores of the forward launch's spectra.
+# round-6 GPU session 9: the whole suite on the new instruction selection (fused butterflies, DPP selects, fresh exchange addresses), then
+# A/B on one box against the tuning builds abl/old.so (rounds 1 - 5 selection) and abl/nofresh.so (exchange addresses shared across the
+# transform: 9 spilled dwords instead of 4), headline / chain / N = 2048 / N = 1024 / config 4, and the long-kernel engines.
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
 O=gpurun_out/r6s9
 mkdir -p $O
-for r in 1 2; do for l in upols_base upols_mac3 upols_znt; do
-  echo "== lib=[$l]" | tee -a $O/upols_policies.txt
-  ADSP_LIB=$PWD/abl/$l.so timeout 300 python tools/bench_upols.py --only upols 2>&1 | tail -1 | tee -a $O/upols_policies.txt
+timeout 2400 python -m pytest tests -q -m gpu -rf -x > $O/pytest_all.log 2>&1
+echo "pytest(all gpu) rc=$?"; grep -E "passed|failed" $O/pytest_all.log | tail -2
+B="python bench.py --no-cpu-baseline --no-stream-extra --no-latency --no-configs --steps 8 --warmup 4"
+ab() {  # ab "<bench args>" lib...
+  args=$1; shift
+  for r in 1 2 3; do for l in "$@"; do
+    if [ "$l" = default ]; then lib=""; else lib="abl/$l.so"; fi
+    echo "$l $(ADSP_LIB=$lib timeout 300 $B $args 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["value"], d["roofline"]["avg_launch_us"], d["roofline"]["frac"], d["roofline"].get("shader_mhz"), d.get("max_rel_err"))')"
+  done; done
+}
+echo "== headline (config 2 batch)" | tee $O/ab.txt
+ab "" old nofresh default 2>&1 | tee -a $O/ab.txt
+echo "== chain (config 5)" | tee -a $O/ab.txt
+ab "--filter chain --chunk 8192 --fs 96000" old nofresh default 2>&1 | tee -a $O/ab.txt
+echo "== config 4 (highcut, 8192 ch)" | tee -a $O/ab.txt
+ab "--filter highcut --channels 8192" old default 2>&1 | tee -a $O/ab.txt
+echo "== N = 2048 batch (M = 4096 two-wave plan)" | tee -a $O/ab.txt
+ab "--chunk 2048 --channels 8192" old nofresh default 2>&1 | tee -a $O/ab.txt
+echo "== N = 1024 batch (M = 2048 one-wave plan)" | tee -a $O/ab.txt
+ab "--chunk 1024 --channels 16384" old nofresh default 2>&1 | tee -a $O/ab.txt
+echo "== EQ, N = 4096 batch (complex spectrum)" | tee -a $O/ab.txt
+ab "--filter eq3" old default 2>&1 | tee -a $O/ab.txt
+echo "== long kernels (tools/bench_upols.py --only upols), old / default alternating" | tee -a $O/ab.txt
+for r in 1 2; do for l in old default; do
+  if [ "$l" = default ]; then lib=""; else lib="abl/$l.so"; fi
+  echo "$l $(ADSP_LIB=$lib timeout 300 python tools/bench_upols.py --only upols 2>/dev/null | tail -1 | cut -c1-900)" | tee -a $O/ab.txt
 done; done
