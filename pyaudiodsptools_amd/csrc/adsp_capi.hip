@@ -219,7 +219,7 @@ int launch(adsp_engine* e, const void* d_in, void* d_out, int n_steps, hipStream
     // stay in L2 for the neighbouring blocks of the channel
     a.nt_lo = 0;
     a.nt_hi = pl.P / 2;
-    if (pl.P >= 64 && !e->generic && n_steps > 1 && !(getenv("ADSP_NT_HYBRID") && atoi(getenv("ADSP_NT_HYBRID")) == 0)) {  // (ADSP_NT_HYBRID=0: tuning A/B)
+    if (pl.M >= 16384 && !e->generic && n_steps > 1 && !(getenv("ADSP_NT_HYBRID") && atoi(getenv("ADSP_NT_HYBRID")) == 0)) {  // (ADSP_NT_HYBRID=0: tuning A/B)
         const int seg = 4 * pl.T, overlap = (c.fft_size - a.V + seg - 1) / seg;
         if (2 * overlap < pl.P / 2) {
             a.nt_lo = overlap;

@@ -542,10 +542,11 @@ UpolsPlan upols_plan() {
     return p;
 }
 
-// B = 16384 as 32 points per thread in 512 threads (radices 32 x 32 x 16, half-buffer exchange): 64 accumulators instead of 128 leave the
-// multiply launch room for four stages of requests instead of two - twice the bytes in flight per wave at half the bytes per output sample
+// Blocks of 16384 stay on 64 points per thread in 256 threads here: as 32 points per thread in 512 threads (what the single-transform engines
+// run since round 6, plan_table.hpp) the multiply launch has room for four stages of requests instead of two, but a call took +11 % / +9 %
+// at 1024 channels (profiles/r6_upols_block_16384_512_threads.txt)
 #ifndef ADSP_UPOLS_PLAN_16384
-#define ADSP_UPOLS_PLAN_16384 ADSP_PLAN_16384
+#define ADSP_UPOLS_PLAN_16384 ADSP_PLAN_16384_64PT
 #endif
 const UpolsPlan* upols_plans(int* count) {
     static const UpolsPlan plans[] = {upols_plan<ADSP_PLAN_8192>(), upols_plan<ADSP_UPOLS_PLAN_16384>()};

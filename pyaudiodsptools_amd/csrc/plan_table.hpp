@@ -65,8 +65,17 @@ namespace f64 {
 #ifndef ADSP_PLAN_8192
 #define ADSP_PLAN_8192 Plan<8192, 32, 3, 32, 16, 16, 1, false, true, 4, 3>
 #endif
+// M = 16384 (round 6): 32 points per thread in 512 threads, radices 32 x 32 x 16, half exchange (64 KiB): two workgroups of eight waves
+// per CU at 128 VGPRs.  Rounds 2 - 5 ran 64 points per thread in 256 threads (16 x 32 x 32, 239 VGPRs, two waves per SIMD:
+// ADSP_PLAN_16384_64PT), against which this form was +0.5 ... 2 % in round 5; this round's instruction-level rework (fused butterflies,
+// DPP selects, hand-split exchange addresses) returned two to three times as much to the 32-point plans, and the A/B now reads
+// +8.3 % for the fused chain (config 5) and +7.8 % for the EQ at N = 8192 (profiles/r6_fused_butterflies_ab.txt, session 13a).
+// The long-kernel engines keep the 64-point form for their blocks of 16384 (adsp_upols.hip: measured there, the other way round).
 #ifndef ADSP_PLAN_16384
-#define ADSP_PLAN_16384 Plan<16384, 64, 3, 16, 32, 32, 1, false, true, 2>
+#define ADSP_PLAN_16384 Plan<16384, 32, 3, 32, 32, 16, 1, false, true, 4, 3>
+#endif
+#ifndef ADSP_PLAN_16384_64PT
+#define ADSP_PLAN_16384_64PT Plan<16384, 64, 3, 16, 32, 32, 1, false, true, 2>
 #endif
 // M = 3072 = 3 * 2^10 (round 3): the F = 1.5 N window of single-step launches of the cut filters at N = 4096 - N + 2d samples
 // is all their kept chunk needs, a 2N transform does 37 % more butterfly work per kept sample.  48 points per thread,
