@@ -216,7 +216,7 @@ __global__ __launch_bounds__(PL::T, PL::P > 32 ? 2 : (PL::T > 256 ? 4 : 3)) void
         for (int u = 0; u < P / 2; u += 2) {  // two register pairs per exchange (fftconv_core.inc: lane_pair_exchange4)
             const float ea[4] = {raw[u].x, raw[u].y, raw[u + 1].x, raw[u + 1].y}, eb[4] = {raw[u].z, raw[u].w, raw[u + 1].z, raw[u + 1].w};
             float an[4], bn[4];
-            lane_pair_exchange4<(ADSP_DPP_SELECT & 1) && P < 64>(ea, eb, an, bn, odd);
+            lane_pair_exchange4<(ADSP_DPP_SELECT & 1) && (P < 64 || ADSP_P64_DPP)>(ea, eb, an, bn, odd);
             xr[2 * u] = an[0];
             xi[2 * u] = an[1];
             xr[2 * u + 1] = bn[0];
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(PL::T, PL::P > 32 ? 2 : (PL::T > 256 ? 4 : 3)) void
     }
     int ja, jb;
     upols_indices<PL>(tid, ja, jb);
-    run_passes<PL, false, 0, const real4* __restrict__>(xr, xi, lds, a.tw, tid, ja, jb);
+    run_passes<PL, false, 0, const real4* __restrict__, (PL::P > 32 ? 1 : -1)>(xr, xi, lds, a.tw, tid, ja, jb);  // (64 points per thread: a laundered lane index per exchange, +10 % here - fftconv_core.inc: lane_mode)
 
     int slot = a.slot_first + blk;
     slot -= slot >= a.R ? a.R : 0;
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(PL::T, ADSP_UPOLS_MAC_WAVES) void upols_mac_kernel(
     }
     int ja, jb;
     upols_indices<PL>(tid, ja, jb);
-    run_passes<PL, true, 0, const real4* __restrict__>(ai, ar, lds, a.tw, tid, ja, jb);  // inverse = forward on swapped parts
+    run_passes<PL, true, 0, const real4* __restrict__, (PL::P > 32 ? 1 : -1)>(ai, ar, lds, a.tw, tid, ja, jb);  // inverse = forward on swapped parts
 
     if (a.epi_op == ADSP_EFFECT_TREMOLO) {
         // the LFO's time base is the stream's own: register m of thread tid holds output times tau, tau + 1 with
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(PL::T, ADSP_UPOLS_MAC_WAVES) void upols_mac_kernel(
             swx = lane_xor1_u(odd ? w0 : w1);
         } else if ((u & 1) == 0) {
             const float xa[4] = {ar[2 * u], ai[2 * u], ar[2 * u + 2], ai[2 * u + 2]}, xb[4] = {ar[2 * u + 1], ai[2 * u + 1], ar[2 * u + 3], ai[2 * u + 3]};
-            lane_pair_exchange4<(ADSP_DPP_SELECT & 2) && P < 64>(xa, xb, ea, eb, odd);
+            lane_pair_exchange4<(ADSP_DPP_SELECT & 2) && (P < 64 || ADSP_P64_DPP)>(xa, xb, ea, eb, odd);
         }
         if (tau >= 0 && tau < total) {  // (the ends of a call cut a block: multiples of 4 samples on both sides)
             int k, r;
