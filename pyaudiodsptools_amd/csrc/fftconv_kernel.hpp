@@ -48,7 +48,7 @@
 // ADSP_ABLATE: tuning-only bitmask that removes one ingredient of the kernel to see what it costs
 // (results are then wrong).  1: pass twiddles not loaded  2: pair tables not loaded  4: no LDS exchange
 // 8: no global input loads  16: no output stores  32: butterflies replaced by copies  64: I/O aliased onto 8 channels
-// 8192: half-buffer exchanges forward 0 -> 1 and last inverse without their workgroup barriers.  Never set in product builds.
+// 8192: half-buffer exchanges forward 0 -> 1 and last inverse without their workgroup barriers.  16384: twiddle powers not formed.  Never set in product builds.
 #ifndef ADSP_ABLATE
 #define ADSP_ABLATE 0
 #endif
