@@ -18,7 +18,10 @@ import numpy as np
 
 from . import config
 from .design import FirStream
+from .effects import MixSignals, VolumeChange  # noqa: F401  (the rest of the reference's Utility.py: this module is `Utility`)
 from .engine import ExactFirEngine, FirEngine, make_engine
+from .signals import (Convert16BitTodBV, ConvertdBVTo16Bit, Dither16BitTo8Bit, Dither32BitIntTo16BitInt,  # noqa: F401
+                      InfodBV, InfodBV16Bit)
 
 
 # ---- the reference's chunk plumbing ---------------------------------------------------------
