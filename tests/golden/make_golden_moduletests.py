@@ -16,6 +16,13 @@ each loop (so stage k is both the reference's output of device k and the input i
 generators' first samples for the same arguments, the utility helpers' values on the sine (ConvertdBVTo16Bit, Convert16BitTodBV,
 InfodBV, InfodBV16Bit, VolumeChange) and the band edges / level of CreateWhitenoise (its phases are unseeded random numbers: only its
 magnitude spectrum is a fixed quantity).  Only numbers the reference produced are stored.
+
+The file also holds the reference's GPU harness, ModuleTestsGPU.py: 44100 Hz / 88200 samples (:35), the chunked sine as ONE 2-D device array
+(:58, `cupy.array(MakeChunks(...))`), LowCutGPU(200) -> HighCutGPU(8000) -> EQ3BandFFTGPU(100, 2, 700, -4, 8000, 5), each loop assigning
+`arr[i] = dev.apply(arr[i])` (:78-110) - Example4's in-place pattern three times over.  cupy is not installed here; the twins' apply() is
+the numpy classes' statement for statement (EffectFFTFilterGPU.py:66-78 = EffectFFTFilter.py:63-75), so the numpy classes run the harness on
+a numpy 2-D array.  Stored for 4 chunks, every 16th sample: `gpu_inplace_k` = the array after loop k (what the script computes),
+`gpu_clean_k` = the same devices fed from separate arrays (the filtered stream; what the in-place rows would hold without the aliasing).
 """
 import contextlib
 import copy
@@ -98,10 +105,35 @@ def main():
     kat["dither16_dtype"] = np.array(str(d16.dtype))
     kat["dither8_offsets"] = np.unique(np.clip(np.around(i16 / 256), -127, 127) - d8)
     kat["dither16_offsets"] = np.unique(np.clip(np.around(i32 / 65535), -32767, 32767) - d16)
+    gpu_harness(kat)
     np.savez_compressed(os.path.join(HERE, "kat_moduletests.npz"), **kat)
     for k in sorted(kat):
         v = kat[k]
         print(k, v.dtype, v.shape, (float(np.abs(v).max()) if v.dtype.kind in "fi" and v.size else v))
+
+
+GPU_N, GPU_CHUNKS, GPU_DEC = 88200, 4, 16    # ModuleTestsGPU.py:35; the script runs 30 chunks
+
+
+def gpu_harness(kat):
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref.config.initialize(FS, GPU_N, use_gpu=True)
+        sine = ref.CreateSinewave(1000, GPU_N * GPU_CHUNKS)
+        make = [lambda: ref.CreateLowCutFilter(200), lambda: ref.CreateHighCutFilter(8000),
+                lambda: ref.CreateEQ3BandFFT(100, 2, 700, -4, 8000, 5)]
+        arr = np.array(ref.MakeChunks(copy.deepcopy(sine)))      # one 2-D array, rows overwritten in place
+        clean = [np.array(c) for c in ref.MakeChunks(copy.deepcopy(sine))]
+        assert arr.dtype == np.float32 and arr.shape == (GPU_CHUNKS, GPU_N)
+        for k, mk in enumerate(make, start=1):
+            dev = mk()
+            for i in range(len(arr)):
+                arr[i] = dev.apply(arr[i])
+            kat[f"gpu_inplace_{k}"] = arr.reshape(-1)[::GPU_DEC].copy()
+            dev = mk()
+            clean = [dev.apply(c) for c in clean]
+            kat[f"gpu_clean_{k}"] = np.concatenate(clean).astype(np.float32)[::GPU_DEC]
+        ref.config.initialize(FS, N)
+    kat["gpu_shape"] = np.array([GPU_CHUNKS, GPU_N, GPU_DEC])
 
 
 if __name__ == "__main__":

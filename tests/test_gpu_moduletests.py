@@ -126,3 +126,53 @@ def test_the_whole_harness_end_to_end(ref_layout, kat):
     assert sine_copy.dtype == np.float32 and len(sine_copy) == len(kat["stage_10"]) and np.abs(sine_copy).max() <= 1.0
     assert np.array_equal(sine_full, kat["sine"]), "the generator's array is not touched by the loops"
     assert "pyAudioDspTools" in sys.modules and sys.modules["pyAudioDspTools"].__name__ == "pyaudiodsptools_amd"
+
+
+@pytest.mark.parametrize("alias_history", [False, True])
+def test_the_gpu_harness(ref_layout, kat, alias_history):
+    """ModuleTestsGPU.py as written, torch CUDA tensors standing in for cupy arrays: chunk 88200 (:35), the chunked sine as ONE 2-D device
+    array (:58), LowCutGPU(200) -> HighCutGPU(8000) -> EQ3BandFFTGPU (:63-65), every loop `arr[i] = dev.apply(arr[i])` (:78-110).  The
+    reference's devices keep views of the rows, so its loops filter their own previous outputs: the script's 1 kHz sine, which all three
+    devices pass, leaves it 220 dB down (kat: gpu_inplace_3).  Default here = the filtered stream (the documented divergence,
+    INTEGRATION.md section 1); alias_history=True = what the script computes."""
+    import copy
+    import torch
+    pyAudioDspTools = ref_layout
+    chunks, n, dec = (int(v) for v in kat["gpu_shape"])
+    pyAudioDspTools.config.initialize(44100, n, use_gpu=True)                           # ModuleTestsGPU.py:35
+    try:
+        from pyAudioDspTools import config
+        from pyAudioDspTools.Generators import CreateSinewave
+        from pyAudioDspTools.Utility import MakeChunks
+        from pyAudioDspTools.EffectFFTFilterGPU import CreateHighCutFilterGPU, CreateLowCutFilterGPU
+        from pyAudioDspTools.EffectEQ3BandFFTGPU import CreateEQ3BandFFTGPU
+        assert config.use_gpu is True and config._gpu_available is True and config.chunk_size == n
+        sine_full = CreateSinewave(1000, chunks * n)
+        sine_copy = copy.deepcopy(sine_full)
+        sine_chunked = torch.from_numpy(np.array(MakeChunks(sine_copy))).cuda()        # cupy.array(MakeChunks(sine_copy)) in the script
+        extra = {"alias_history": True} if alias_history else {}
+        lowcuttest = CreateLowCutFilterGPU(200, **extra)
+        highcuttest = CreateHighCutFilterGPU(8000, **extra)
+        eq3bandffttestgpu = CreateEQ3BandFFTGPU(100, 2, 700, -4, 8000, 5, **extra)
+        before = 1.0                                                                    # magnitude of what the loop's windows hold
+        for k, dev in enumerate((lowcuttest, highcuttest, eq3bandffttestgpu), start=1):
+            counter = 0
+            for counter in range(len(sine_chunked)):
+                sine_chunked[counter] = dev.apply(sine_chunked[counter])
+                counter += 1
+            got = sine_chunked.cpu().numpy().reshape(-1)[::dec]
+            if not alias_history:
+                assert_parity(got, kat[f"gpu_clean_{k}"], what=f"loop {k}: the filtered stream")
+                continue
+            # a feedback loop (each call re-filters earlier outputs) fed by the previous loop's rounding: north_star's bound on the
+            # magnitude of the data in the windows - the rows as the loop found them - for this loop's rounding plus the previous loop's
+            want = kat[f"gpu_inplace_{k}"]
+            err = np.abs(got.astype(np.float64) - want).max()
+            assert err <= 2e-5 * before, (k, err, before)
+            before = float(np.abs(want).max())
+        if alias_history:
+            assert np.abs(got).max() < 1e-6      # the script's result: silence
+        else:
+            assert np.abs(got).max() > 1.0       # the filtered sine (the EQ's +2 ... +5 dB shelves around a 1 kHz tone)
+    finally:
+        pyAudioDspTools.config.initialize(44100, 512)

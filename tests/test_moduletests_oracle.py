@@ -64,3 +64,25 @@ def test_the_whole_harness_end_to_end(kat):
         want = kat[f"stage_{k:02d}"]
         assert np.abs(stream.astype(np.float64) - want).max() <= 2e-6 * max(1.0, np.abs(want).max()), str(kat["stage_names"][k - 1])
     assert stream.dtype == np.float32 and np.abs(stream).max() <= 1.0  # the soft clipper ends the chain inside [-1, 1]
+
+
+def test_the_gpu_harness_in_place_loops(kat):
+    """ModuleTestsGPU.py:35-110: chunk 88200, ONE 2-D array, three devices in a row, every loop `arr[i] = dev.apply(arr[i])`.  The devices
+    keep views of the rows (EffectFFTFilterGPU.py:66-68), so each loop filters its own previous outputs - the oracle keeps references like
+    the reference and reproduces both the in-place arrays and the clean streams."""
+    chunks, n, dec = (int(v) for v in kat["gpu_shape"])
+    sine = np.float32(np.sin(2 * np.pi * 1000 * np.arange(chunks * n) / FS))
+    make = [lambda: orc.OracleLowCut(200, FS, n), lambda: orc.OracleHighCut(8000, FS, n),
+            lambda: orc.OracleEQ3BandFFT(100, 2, 700, -4, 8000, 5, FS, n)]
+    arr = sine.reshape(chunks, n).copy()
+    clean = [c.copy() for c in sine.reshape(chunks, n)]
+    for k, mk in enumerate(make, start=1):
+        dev = mk()
+        for i in range(len(arr)):
+            arr[i] = dev.apply(arr[i])
+        assert np.array_equal(arr.reshape(-1)[::dec], kat[f"gpu_inplace_{k}"]), k
+        dev = mk()
+        clean = [dev.apply(c) for c in clean]
+        assert np.array_equal(np.concatenate(clean)[::dec], kat[f"gpu_clean_{k}"]), k
+    # what the aliasing does to the script's signal: a 1 kHz sine, which all three devices pass, comes out 220 dB down
+    assert np.abs(kat["gpu_clean_3"]).max() > 1.0 and np.abs(kat["gpu_inplace_3"]).max() < 1e-10
