@@ -9,6 +9,8 @@
 // reach further back than the caches hold, less otherwise.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include <vector>
 
 #include "../../include/adsp.h"
@@ -238,6 +240,19 @@ int adsp_delay_apply_host(adsp_delay* e, const float* in, float* out, int n_step
     if (n_steps <= 0) return fail(ADSP_ERR_ARG, "n_steps must be positive");
     HIP_TRY(hipSetDevice(e->cfg.device_id));
     const size_t elems = (size_t)n_steps * e->plane();
+    if (elems * sizeof(float) <= adsp::kHostWindowMax) {  // a chunk or a few: the kernel reads / writes pinned host memory (capi_common.hpp)
+        adsp::HostWindow* w = adsp::host_window(e->cfg.device_id);
+        if (!w) return ADSP_ERR_ARG;
+        std::lock_guard<std::mutex> lock(w->mu);
+        int rc = adsp::host_window_reserve(*w, elems * sizeof(float), elems * sizeof(float));
+        if (rc) return rc;
+        memcpy(w->in, in, elems * sizeof(float));
+        if (e->accumulate) memcpy(w->out, out, elems * sizeof(float));
+        if ((rc = adsp_delay_apply_device(e, static_cast<const float*>(w->d_in), static_cast<float*>(w->d_out), n_steps, nullptr))) return rc;
+        if ((rc = adsp::host_window_wait(*w, nullptr))) return rc;
+        memcpy(out, w->out, elems * sizeof(float));
+        return ADSP_OK;
+    }
     if (elems > e->stage_elems) {
         HIP_TRY(hipDeviceSynchronize());
         if (e->stage_in) (void)hipFree(e->stage_in);

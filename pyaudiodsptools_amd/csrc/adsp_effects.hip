@@ -3,6 +3,7 @@
 // (adsp_nonfinite_guard) and the shader-clock probe of bench.py.  No engine object here.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
 #include <vector>
 
 #include "../../include/adsp.h"
@@ -10,6 +11,49 @@
 #include "plan_table.hpp"
 
 using adsp::fail;
+
+namespace adsp {
+namespace {
+constexpr int kMaxWindows = 64;
+HostWindow g_windows[kMaxWindows];  // never freed: pinned memory of a process that is about to exit is the driver's to release
+}  // namespace
+
+HostWindow* host_window(int device_id) {
+    int ndev = 0;
+    if (adsp_device_count(&ndev)) return nullptr;
+    if (device_id < 0 || device_id >= ndev || device_id >= kMaxWindows) {
+        fail(ADSP_ERR_ARG, "device_id %d out of range (%d devices)", device_id, ndev);
+        return nullptr;
+    }
+    return &g_windows[device_id];
+}
+
+int host_window_reserve(HostWindow& w, size_t in_bytes, size_t out_bytes) {
+    struct Side { char** host; void** dev; size_t* cap; size_t want; } sides[2] = {{&w.in, &w.d_in, &w.cap_in, in_bytes}, {&w.out, &w.d_out, &w.cap_out, out_bytes}};
+    for (Side& s : sides) {
+        if (s.want <= *s.cap) continue;
+        if (*s.host) {
+            HIP_TRY(hipDeviceSynchronize());  // (calls hold the mutex until they are done: nothing reads the old buffer, this is belt and braces)
+            (void)hipHostFree(*s.host);
+            *s.host = nullptr;
+            *s.cap = 0;
+        }
+        size_t cap = size_t(64) << 10;
+        while (cap < s.want) cap *= 2;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(s.host), cap, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer(s.dev, *s.host, 0));
+        *s.cap = cap;
+    }
+    if (!w.done) HIP_TRY(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
+    return ADSP_OK;
+}
+
+int host_window_wait(HostWindow& w, hipStream_t stream) {
+    HIP_TRY(hipEventRecord(w.done, stream));
+    HIP_TRY(hipEventSynchronize(w.done));
+    return ADSP_OK;
+}
+}  // namespace adsp
 
 // standalone elementwise form of the fused output effects (fftconv_kernel.hpp::epilogue_value): out[i] = effect(in[i]);
 // the tremolo multiplies by its periodic LFO table, element 0 at table index `phase`
@@ -182,6 +226,21 @@ int adsp_mix_host(int device_id, const float* const* inputs, int k, int clip, fl
     if (device_id < 0 || device_id >= ndev) return fail(ADSP_ERR_ARG, "device_id %d out of range (%d devices)", device_id, ndev);
     HIP_TRY(hipSetDevice(device_id));
     if (n == 0) return ADSP_OK;
+    if ((size_t)k * n * sizeof(float) <= adsp::kHostWindowMax) {  // small: the kernel reads the inputs from pinned host memory
+        adsp::HostWindow* w = adsp::host_window(device_id);
+        if (!w) return ADSP_ERR_ARG;
+        std::lock_guard<std::mutex> lock(w->mu);
+        if ((rc = adsp::host_window_reserve(*w, (size_t)k * n * sizeof(float), n * sizeof(float)))) return rc;
+        std::vector<const float*> win(k);
+        for (int j = 0; j < k; ++j) {
+            memcpy(w->in + (size_t)j * n * sizeof(float), inputs[j], n * sizeof(float));
+            win[j] = static_cast<const float*>(w->d_in) + (size_t)j * n;
+        }
+        if ((rc = adsp_mix_device(device_id, win.data(), k, clip, static_cast<float*>(w->d_out), n, nullptr))) return rc;
+        if ((rc = adsp::host_window_wait(*w, nullptr))) return rc;
+        memcpy(out, w->out, n * sizeof(float));
+        return ADSP_OK;
+    }
     float* d = nullptr;  // [k + 1][n]: the inputs, then the sum
     HIP_TRY(hipMalloc(&d, (size_t)(k + 1) * n * sizeof(float)));
     std::vector<const float*> ptrs(k);
@@ -209,6 +268,17 @@ int adsp_effect_host(int device_id, int effect, float p0, float p1, float p2, in
     if (device_id < 0 || device_id >= ndev) return fail(ADSP_ERR_ARG, "device_id %d out of range (%d devices)", device_id, ndev);
     HIP_TRY(hipSetDevice(device_id));
     if (n == 0) return ADSP_OK;
+    if (n * sizeof(float) <= adsp::kHostWindowMax) {  // a chunk or a few: no allocation, no staging copy (capi_common.hpp)
+        adsp::HostWindow* w = adsp::host_window(device_id);
+        if (!w) return ADSP_ERR_ARG;
+        std::lock_guard<std::mutex> lock(w->mu);
+        if ((rc = adsp::host_window_reserve(*w, n * sizeof(float), n * sizeof(float)))) return rc;
+        memcpy(w->in, in, n * sizeof(float));
+        if ((rc = pointwise_launch(device_id, effect, p0, p1, p2, phase, static_cast<const float*>(w->d_in), static_cast<float*>(w->d_out), n, nullptr))) return rc;
+        if ((rc = adsp::host_window_wait(*w, nullptr))) return rc;
+        memcpy(out, w->out, n * sizeof(float));
+        return ADSP_OK;
+    }
     float* d = nullptr;
     HIP_TRY(hipMalloc(&d, n * sizeof(float)));
     hipError_t err = hipMemcpy(d, in, n * sizeof(float), hipMemcpyHostToDevice);

@@ -13,6 +13,7 @@
 // numbers are in DESIGN.md section 6f.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
 #include <vector>
 
 #include "../../include/adsp.h"
@@ -431,6 +432,18 @@ int adsp_scan_apply_host(adsp_scan* e, const float* in, float* out, int n_steps)
     if (n_steps <= 0) return fail(ADSP_ERR_ARG, "n_steps must be positive");
     HIP_TRY(hipSetDevice(e->cfg.device_id));
     const size_t elems = (size_t)n_steps * e->cfg.n_channels * e->cfg.chunk_size;
+    if (elems * sizeof(float) <= adsp::kHostWindowMax) {  // a chunk or a few: the kernel reads / writes pinned host memory (capi_common.hpp)
+        adsp::HostWindow* w = adsp::host_window(e->cfg.device_id);
+        if (!w) return ADSP_ERR_ARG;
+        std::lock_guard<std::mutex> lock(w->mu);
+        int rc = adsp::host_window_reserve(*w, elems * sizeof(float), elems * sizeof(float));
+        if (rc) return rc;
+        memcpy(w->in, in, elems * sizeof(float));
+        if ((rc = adsp_scan_apply_device(e, static_cast<const float*>(w->d_in), static_cast<float*>(w->d_out), n_steps, nullptr))) return rc;
+        if ((rc = adsp::host_window_wait(*w, nullptr))) return rc;
+        memcpy(out, w->out, elems * sizeof(float));
+        return ADSP_OK;
+    }
     if (elems > e->stage_elems) {
         HIP_TRY(hipDeviceSynchronize());
         if (e->stage) (void)hipFree(e->stage);

@@ -341,3 +341,49 @@ def test_mix_signals_and_mix_bus(adsp, golden):
     od = [o.OracleLowCut(300, 44100, n), o.OracleHighCut(5000, 44100, n), o.OracleLowCut(2000, 44100, n)]
     want = np.concatenate([fx.mix_signals(*[od[k].apply(xs[k][i * n:(i + 1) * n]) for k in range(3)]) for i in range(4)])
     assert_parity(d_out.cpu().numpy().reshape(-1), want, what="mix bus N=1000")
+
+
+def test_small_host_calls_through_the_pinned_window(adsp):
+    """Host calls of up to 1 MiB run with the kernel reading and writing ONE pinned, mapped buffer pair per device (capi_common.hpp: no
+    allocation or staging copy per call - the reference's own pattern is one chunk per call); larger ones keep the staging copies.  Both
+    forms give the same bits either side of the limit, the window grows with the call, and the mix bus reads all its inputs from it."""
+    from oracle import effects_oracle as fx
+    limit = (1 << 20) // 4  # samples
+    clip = adsp.CreateSoftClipper(0.7)
+    big = seeded_stream(31, limit + 8) * np.float32(1.4)
+    whole = clip.apply(big)                      # staging path
+    for n in (1, 3, 512, 16384 + 1, 70000, limit - 1, limit):   # window path: first 64 KiB, then grown twice
+        assert np.array_equal(clip.apply(big[:n]), whole[:n]), n
+    assert np.array_equal(clip.apply(big[:limit + 1]), whole[:limit + 1])
+    assert_parity(whole, fx.soft_clipper(big, 0.7))
+    parts = [seeded_stream(40 + j, 5000) for j in range(5)]
+    assert_parity(adsp.MixSignals(*parts), fx.mix_signals(*parts), what="mix bus, five inputs in the window")
+    wide = [seeded_stream(50 + j, limit) for j in range(2)]          # 2 MiB of inputs: staging path
+    assert_parity(adsp.MixSignals(*wide), fx.mix_signals(*wide), what="mix bus, staging path")
+
+
+def test_small_host_calls_from_two_threads(adsp):
+    """The window is shared per device and locked for the length of a call: effects, a delay line and a compressor called from two threads
+    at once return what they return alone."""
+    import threading
+    adsp.config.initialize(44100, 512)
+    try:
+        x = (seeded_stream(61, 200 * 512) * np.float32(1.3)).reshape(200, 512)
+        def run(make, out):
+            dev = make()
+            out.append(np.stack([dev.apply(c) for c in x]))
+        makers = [adsp.CreateSaturator, adsp.CreateDelay, adsp.CreateCompressor, adsp.CreateHardDistortion]
+        alone = []
+        for mk in makers:
+            run(mk, alone)
+        for pair in ((0, 1), (2, 3), (1, 2)):
+            got = {i: [] for i in pair}
+            threads = [threading.Thread(target=run, args=(makers[i], got[i])) for i in pair]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            for i in pair:
+                assert len(got[i]) == 1 and np.array_equal(got[i][0], alone[i]), (pair, i)
+    finally:
+        adsp.config.initialize(44100, 4096)
