@@ -13,6 +13,7 @@
 // numbers are in DESIGN.md section 6f.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -256,6 +257,178 @@ __global__ __launch_bounds__(TILE) void scan_kernel(const ScanArgs a) {
     if (mine) op.save(a, ch);
 }
 
+// Compressor / gate with TIME across the lanes (round 6): one wave = one channel, its 64 lanes = 64 consecutive samples.  What is sequential in
+// the reference's loop nest is only WHICH gain a sample gets - the walk reads the threshold bit of every sample and three counters, never
+// a sample value.  So the wave takes the 64 threshold bits with one ballot, walks the state machine over them in wave-uniform integer
+// code (the scalar unit: no LDS or memory access inside the chain, ~50 cycles per sample instead of ~400 for a lane walking its own
+// LDS row), hands every lane its gain code with one select per step, and then all 64 lanes look their gain up and multiply at once.
+// Same transitions, same tables, same two float32 products as Compressor::sample - bit for bit.  Used up to kWaveScanMaxChannels channels (2048 with envelopes above 16 KiB):
+// beyond that one lane per channel (scan_kernel above) has more channels in flight than the scalar units can walk.
+constexpr int kWaveScanWaves = 4;             // channels per workgroup (they share the staged envelopes)
+// measured (profiles/r6f_scan_time_across_lanes.txt): the compressor's envelopes (6 KiB) leave the CU full of workgroups and the form wins up
+// to 4096 channels (1.4x there, 2.5x at 1024; -8 % at 8192); the gate's (35 KiB: four workgroups per CU) from 4096 channels on one lane per channel is ahead
+constexpr int kWaveScanMaxChannels = 4096, kWaveScanMaxChannelsBigEnvelopes = 2048;
+
+template <bool ENV_LDS>
+__global__ __launch_bounds__(TILE * kWaveScanWaves) void compressor_wave_kernel(const ScanArgs a) {
+    extern __shared__ float dyn_lds[];
+    const int lane = static_cast<int>(threadIdx.x) & (TILE - 1);
+    const int ch = static_cast<int>(blockIdx.x) * kWaveScanWaves + (static_cast<int>(threadIdx.x) >> 6);
+    const float* table = nullptr;
+    if constexpr (ENV_LDS) {
+        for (int i = static_cast<int>(threadIdx.x); i < a.x_max; i += TILE * kWaveScanWaves) dyn_lds[i] = a.attack[i];
+        for (int i = static_cast<int>(threadIdx.x); i < a.y_max; i += TILE * kWaveScanWaves) dyn_lds[a.x_max + i] = a.release[i];
+        __syncthreads();
+        table = dyn_lds;  // attack[0 .. x_max), release[0 .. y_max) behind it: gain code = index into this
+    }
+    if (ch >= a.C) return;  // (wave-uniform; after the only workgroup barrier)
+    const int x_max = a.x_max, y_max = a.y_max;
+    int x = __builtin_amdgcn_readfirstlane(a.cp_state[ch]);
+    int y = __builtin_amdgcn_readfirstlane(a.cp_state[a.C + ch]);
+    int state = __builtin_amdgcn_readfirstlane(a.cp_state[2 * a.C + ch]);
+    const double ratio = static_cast<double>(x_max) / static_cast<double>(y_max);
+    const float threshold = a.threshold, pre_gain = a.pre_gain;
+    const int tiles_per_chunk = (a.N + TILE - 1) / TILE;
+    const int n_tiles = a.n_steps * tiles_per_chunk;
+    bool full = true, freeze = false;
+    int where = 0;
+
+    auto tile_at = [&](int t, int& w) -> size_t {
+        const int s = t / tiles_per_chunk, t0 = (t - s * tiles_per_chunk) * TILE;
+        w = a.N - t0 < TILE ? a.N - t0 : TILE;
+        return (static_cast<size_t>(s) * a.C + ch) * a.N + t0;
+    };
+    int w0;
+    const size_t base0 = tile_at(0, w0);
+    float pre = lane < w0 ? a.in[base0 + lane] : 0.f;
+    for (int t = 0; t < n_tiles; ++t) {
+        int w;
+        const size_t base = tile_at(t, w);
+        const float v = pre;
+        if (t + 1 < n_tiles) {  // in flight during the walk below
+            int wn;
+            const size_t bn = tile_at(t + 1, wn);
+            pre = lane < wn ? a.in[bn + lane] : 0.f;
+        }
+        if (t % tiles_per_chunk == 0) {  // the loop nest restarts with every chunk (Compressor::begin_chunk)
+            full = true;
+            freeze = false;
+            where = 0;
+        }
+        const unsigned long long above_bits = __ballot(lane < w && fabsf(v) > threshold);
+        int code = -1;  // this lane's gain: -1 untouched (x 1.0f), else index into attack ++ release
+        int k = 0;
+        while (k < w) {
+            // Steady positions of the walk: a RUN of samples that Compressor::sample would consume one by one without moving - resting
+            // until the next sample above the threshold, the attack ramp (whatever the samples are), the hold while they stay above, the
+            // release ramp while they stay below.  One step per run: its length from the threshold bits (count of trailing zeros / ones),
+            // the lanes of the run take their codes at once.  Everything else - the transitions - goes through the walk below.
+            const unsigned long long rest = above_bits >> k;  // bit 0 = sample k; zero beyond the tile
+            int n = 0, first = -1, stride = 0;
+            if (where == 0 && x == 0 && y == 0) {
+                n = rest ? __builtin_ctzll(rest) : TILE;
+            } else if (where == 1 && state == 1 && x < x_max) {
+                n = x_max - x;
+                first = x;
+                stride = 1;
+            } else if (where == 2 && state == 1) {
+                n = ~rest ? __builtin_ctzll(~rest) : TILE;
+                first = x_max - 1;
+            } else if (where == 3 && state == 2 && y < y_max) {
+                n = rest ? __builtin_ctzll(rest) : TILE;
+                n = n < y_max - y ? n : y_max - y;
+                first = x_max + y;
+                stride = 1;
+            }
+            n = n < w - k ? n : w - k;
+            if (n > 0) {
+                if (first >= 0 && lane >= k && lane < k + n) code = first + (lane - k) * stride;
+                if (where == 1) x += n;
+                if (where == 3) {
+                    y += n;
+                    x = 0;
+                }
+                k += n;
+                continue;
+            }
+            const bool above = rest & 1ull;
+            int c = -1;
+            bool done = false;
+            for (int visit = 0; visit < 8 && !done; ++visit) {  // Compressor::sample's walk, on wave-uniform values
+                if (where == 0) {
+                    if (above || x != 0 || y != 0) {
+                        if (full && state == 0) {
+                            x = 0;
+                            state = 1;
+                        }
+                        if (!full && state == 2) {
+                            x = x_max - __builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<double>(y) * ratio));
+                            freeze = false;
+                            state = 1;
+                        }
+                        where = 1;
+                    } else {
+                        done = true;
+                    }
+                } else if (where == 1) {
+                    if (x < x_max && state == 1) {
+                        c = x++;
+                        done = true;
+                    } else {
+                        where = 2;
+                    }
+                } else if (where == 2) {
+                    if (above && state == 1) {
+                        c = x_max - 1;
+                        done = true;
+                    } else {
+                        state = 2;
+                        where = 3;
+                    }
+                } else {
+                    bool consumed = false;
+                    if (y < y_max && state == 2) {
+                        x = 0;
+                        if (!above) {
+                            c = x_max + y++;
+                            consumed = true;
+                        } else {
+                            full = false;
+                            y = 0;
+                            freeze = true;
+                        }
+                    }
+                    if (consumed) {
+                        done = true;
+                    } else {
+                        if (y == y_max) {
+                            full = true;
+                            state = 0;
+                            x = 0;
+                            y = 0;
+                        }
+                        where = 0;
+                        done = !freeze;
+                    }
+                }
+            }
+            code = lane == k ? c : code;
+            ++k;
+        }
+        float gain = 1.0f;
+        if (code >= 0) {
+            if constexpr (ENV_LDS) gain = table[code];
+            else gain = code < x_max ? a.attack[code] : a.release[code - x_max];
+        }
+        if (lane < w) a.out[base + lane] = (v * pre_gain) * gain;
+    }
+    if (lane == 0) {
+        a.cp_state[ch] = x;
+        a.cp_state[a.C + ch] = y;
+        a.cp_state[2 * a.C + ch] = state;
+    }
+}
+
 template <class Op>
 void launch_scan(const ScanArgs& a, size_t dyn_lds, hipStream_t stream) {
     // channels per wave: as few as it takes to put >= 1024 waves on the chip (256 CUs x 4 SIMDs)
@@ -419,6 +592,12 @@ int adsp_scan_apply_device(adsp_scan* e, const float* d_in, float* d_out, int n_
             case 3: launch_scan<Biquad<3>>(a, 0, (hipStream_t)stream); break;
             default: launch_scan<Biquad<4>>(a, 0, (hipStream_t)stream); break;
         }
+    } else if (a.C <= (env_bytes > 16 * 1024 ? kWaveScanMaxChannelsBigEnvelopes : kWaveScanMaxChannels) && !getenv("ADSP_SCAN_LANE_PER_CHANNEL")) {  // time across the lanes (the variable: A/B and tests of the other kernel)
+        const unsigned grid = static_cast<unsigned>((a.C + kWaveScanWaves - 1) / kWaveScanWaves);
+        if (a.env_in_lds)
+            hipLaunchKernelGGL(compressor_wave_kernel<true>, dim3(grid), dim3(TILE * kWaveScanWaves), env_bytes, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL(compressor_wave_kernel<false>, dim3(grid), dim3(TILE * kWaveScanWaves), 0, (hipStream_t)stream, a);
     } else if (a.env_in_lds)
         launch_scan<Compressor<true>>(a, env_bytes, (hipStream_t)stream);
     else

@@ -155,3 +155,37 @@ def test_scan_engine_argument_errors(adsp):
     assert np.array_equal(y[0, 0], np.concatenate([[0], x[0, 0, :-1]])) and y[1, 0, 0] == x[0, 0, -1]
     with pytest.raises(ValueError):
         eng.apply_host(np.zeros((2, 3, 8), np.float32))
+
+
+@pytest.mark.parametrize("kind", ["compressor", "gate"])
+@pytest.mark.parametrize("n,C,steps", [(100, 5, 7), (1000, 3, 4), (64, 9, 12), (4096, 2, 2), (37, 8200, 2)])
+def test_time_across_lanes_equals_lane_per_channel_and_oracle(adsp, kind, n, C, steps):
+    """Round 6: up to 8192 channels the compressor / gate run with TIME across the lanes of a wave (one ballot of threshold bits, the
+    state machine walked in wave-uniform code, all 64 gains applied at once); beyond that - and with ADSP_SCAN_LANE_PER_CHANNEL set - one
+    lane walks one channel.  Both forms against each other bit for bit on every channel, and against the oracle on a few: ragged tiles
+    (N = 100, 1000, 37), one-tile chunks, envelopes too long for LDS (the gate's 300 ms release), more channels than the limit."""
+    import os
+    from oracle import recursive_oracle as ro
+    adsp.config.initialize(44100, n)
+    rng = np.random.default_rng(n * 31 + C)
+    env = np.repeat(rng.choice([0.02, 0.1, 0.3, 1.0], size=-(-steps * C * n // 16)), 16)[:steps * C * n].astype(np.float32)
+    x = (rng.uniform(-1, 1, steps * C * n).astype(np.float32) * env).reshape(steps, C, n)
+    args = (-18, 0.5, 1.0, 7.5) if kind == "compressor" else (-9, 0.2, 1.0, 300.0 if n == 1000 else 7.5)
+    make = (lambda: adsp.CreateCompressor(*args, channels=C)) if kind == "compressor" else (lambda: adsp.CreateGate(*args, channels=C))
+    keep = os.environ.pop("ADSP_SCAN_LANE_PER_CHANNEL", None)
+    try:
+        dev = make()
+        first = dev.apply_batch(x[:steps // 2])          # state carried from one call to the next
+        got = np.concatenate([first, dev.apply_batch(x[steps // 2:])])
+        os.environ["ADSP_SCAN_LANE_PER_CHANNEL"] = "1"
+        other = make().apply_batch(x)
+    finally:
+        os.environ.pop("ADSP_SCAN_LANE_PER_CHANNEL", None)
+        if keep is not None:
+            os.environ["ADSP_SCAN_LANE_PER_CHANNEL"] = keep
+        adsp.config.initialize(44100, 4096)
+    assert np.array_equal(got, other), int(np.argmax(got != other))
+    for c in sorted({0, C // 2, C - 1}):
+        o = ro.OracleCompressor(44100, *args) if kind == "compressor" else ro.OracleGate(*args)
+        want = np.stack([o.apply(x[s, c]) for s in range(steps)])
+        assert np.array_equal(got[:, c], want), c
