@@ -9,6 +9,7 @@ script written against the reference sees; the batched figures are bench.py's.
 """
 import argparse
 import copy
+import gc
 import json
 import os
 import sys
@@ -57,6 +58,8 @@ def cpu_section(seconds):
     for name, dev in devices:
         out[name] = timed_loop(dev, sine_chunked)
     out["combined_peak"] = float(abs(CombineChunks(sine_chunked)).max())
+    del devices, dev
+    gc.collect()  # the ten devices' GPU memory is released HERE (a destroy waits for the device), not by a collection in the middle of the next section's timed loops
     return out
 
 

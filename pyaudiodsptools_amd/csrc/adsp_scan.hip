@@ -6,7 +6,8 @@
 //                                                 sample is scaled by `depth` first and the envelopes run 1 <-> 1/depth
 //
 // Both carry state from one sample to the next, so time cannot be split across lanes without changing the rounding the
-// reference's loops produce.  What is parallel is the channel axis: ONE LANE PER CHANNEL, 64 channels per workgroup.
+// reference's loops produce.  What is parallel is the channel axis: ONE LANE PER CHANNEL, 64 channels per workgroup (the biquads always; the
+// compressor and the gate from a few thousand channels on - below that compressor_wave_kernel puts time across the lanes, see there).
 // Memory stays coalesced through an LDS tile: the wave loads 64 channels x 64 samples row by row (256 contiguous bytes
 // per row), each lane then walks its own row (rows padded to 65 floats: conflict-free), and the tile is stored back row
 // by row.  Latency-bound by construction (a dependent chain of ~10 float64 operations per sample and section); the
@@ -259,11 +260,15 @@ __global__ __launch_bounds__(TILE) void scan_kernel(const ScanArgs a) {
 
 // Compressor / gate with TIME across the lanes (round 6): one wave = one channel, its 64 lanes = 64 consecutive samples.  What is sequential in
 // the reference's loop nest is only WHICH gain a sample gets - the walk reads the threshold bit of every sample and three counters, never
-// a sample value.  So the wave takes the 64 threshold bits with one ballot, walks the state machine over them in wave-uniform integer
-// code (the scalar unit: no LDS or memory access inside the chain, ~50 cycles per sample instead of ~400 for a lane walking its own
-// LDS row), hands every lane its gain code with one select per step, and then all 64 lanes look their gain up and multiply at once.
-// Same transitions, same tables, same two float32 products as Compressor::sample - bit for bit.  Used up to kWaveScanMaxChannels channels (2048 with envelopes above 16 KiB):
-// beyond that one lane per channel (scan_kernel above) has more channels in flight than the scalar units can walk.
+// a sample value.  So the wave takes the 64 threshold bits with one ballot and walks the state machine over them in wave-uniform integer
+// code (no LDS or memory access inside the chain), and then all 64 lanes look their gain up and multiply at once.  Walking sample by sample
+// that is ~100 scalar instructions per sample at one instruction per four cycles (what ONE wave issues, scalar or vector): 1.5x faster
+// than a lane walking its LDS row, no more.  The walk therefore moves in RUNS: at its four steady positions (resting, attack ramp, hold,
+// release ramp) the length of the run is a count of trailing zeros / ones of the threshold bits, and the lanes of the run take their
+// gain codes in one step - a sine through the default compressor is ~12 steps per 64 samples, a signal below the threshold one.
+// Same transitions, same tables, same two float32 products as Compressor::sample - bit for bit (tests/test_gpu_recursive.py holds the two
+// kernels against each other).  Used up to kWaveScanMaxChannels channels (2048 with envelopes above 16 KiB): beyond that one lane per
+// channel (scan_kernel above) has more channels in flight than one wave per channel can walk.
 constexpr int kWaveScanWaves = 4;             // channels per workgroup (they share the staged envelopes)
 // measured (profiles/r6f_scan_time_across_lanes.txt): the compressor's envelopes (6 KiB) leave the CU full of workgroups and the form wins up
 // to 4096 channels (1.4x there, 2.5x at 1024; -8 % at 8192); the gate's (35 KiB: four workgroups per CU) from 4096 channels on one lane per channel is ahead

@@ -26,6 +26,17 @@ def _lowpass(cutoff_hz, fs, taps, window):
     return h / h.sum()
 
 
+def _convolve(a, b):
+    """Linear convolution of two kernels in float64: numpy's direct sum for short ones, an FFT product (zero-padded to a power of two; error
+    ~1e-15 of the peak, the design goldens hold 1e-12) where the direct sum would take seconds - the EQ's mid band at chunk 88200 is
+    44099 x 44099 taps, 3.4 s of a 3.5 s constructor."""
+    if min(len(a), len(b)) <= 8192:
+        return np.convolve(a, b)
+    n = len(a) + len(b) - 1
+    f = 1 << (n - 1).bit_length()
+    return np.fft.irfft(np.fft.rfft(a, f) * np.fft.rfft(b, f), f)[:n]
+
+
 def _invert(h):
     g = -h
     g[(len(h) - 1) // 2] += 1.0
@@ -66,7 +77,7 @@ def eq3_composite(lowshelf_hz, lowshelf_db, midband_hz, midband_db, highshelf_hz
     c = np.zeros(2 * taps - 1)
     c[:taps] += (10 ** (highshelf_db / 20) - 1) * k["highshelf"]
     c[:taps] += (10 ** (lowshelf_db / 20) - 1) * k["lowshelf"]
-    c += (10 ** (midband_db / 20) - 1) * np.convolve(k["mid_highpass"], k["mid_lowpass"])
+    c += (10 ** (midband_db / 20) - 1) * _convolve(k["mid_highpass"], k["mid_lowpass"])
     c[d] += 1.0
     return c
 
@@ -101,7 +112,7 @@ class FirStream:
     def then(self, other):
         """Series connection: kernels convolve, delays add (chain LowCut -> EQ -> HighCut)."""
         assert other.chunk_size == self.chunk_size
-        return FirStream(np.convolve(self.taps, other.taps), self.chunk_size,
+        return FirStream(_convolve(self.taps, other.taps), self.chunk_size,
                          self.latency_chunks + other.latency_chunks, self.lookahead + other.lookahead)
 
     def trimmed(self, eps=TRIM_EPS):
