@@ -33,6 +33,7 @@
 // every block an output needs inside the input that has arrived (the reference's devices delay by ~3/4 chunk).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -1076,6 +1077,19 @@ int adsp_upols_apply_host(adsp_upols* u, const void* in, void* out, int n_steps)
     if (n_steps <= 0) return fail(ADSP_ERR_ARG, "n_steps must be positive");
     HIP_TRY(hipSetDevice(u->cfg.device_id));
     const size_t bytes = (size_t)n_steps * u->plane_bytes();
+    if (bytes <= adsp::kHostWindowMax && !getenv("ADSP_UPOLS_HOST_STAGED")) {
+        // a chunk of one or two channels (Example4's own call through numpy arrays): the launches read / write pinned host memory (capi_common.hpp)
+        adsp::HostWindow* w = adsp::host_window(u->cfg.device_id);
+        if (!w) return ADSP_ERR_ARG;
+        std::lock_guard<std::mutex> lock(w->mu);
+        int rc = adsp::host_window_reserve(*w, bytes, bytes);
+        if (rc) return rc;
+        memcpy(w->in, in, bytes);
+        if ((rc = adsp_upols_apply_device(u, w->d_in, w->d_out, n_steps, nullptr))) return rc;
+        if ((rc = adsp::host_window_wait(*w, nullptr))) return rc;
+        memcpy(out, w->out, bytes);
+        return ADSP_OK;
+    }
     if (bytes > u->stage_bytes) {
         HIP_TRY(hipDeviceSynchronize());
         if (u->stage_in) (void)hipFree(u->stage_in);
