@@ -12,17 +12,19 @@
 // - one forward transform, P spectrum multiply-accumulates, ONE inverse transform and one store per B samples.  Two launches per
 // call, each over every (channel, block) at once:
 //   upols_forward_kernel : window of 2B samples (generic chunk geometry: any chunk size divisible by 4) -> the plan's forward passes
-//                          -> the thread's registers, as they are, to the delay line.  What is stored is Z = FFT of the packed
-//                          sequence z[n] = x[2n] + i x[2n+1] in the REGISTER LAYOUT of the plan (element e = tid + T m of the
-//                          last forward pass), 8 M bytes per block: the real-FFT split, the product with H_p and the re-packing
-//                          for the inverse are ONE 2x2 complex matrix per bin pair (fftconv_core.inc: pair_op), linear in
-//                          (Z[k], conj Z[M-k]), so the sum over partitions can be taken on the unsplit Z - and both partners of
-//                          a pair live in the same thread; the delay line holds them in 16-byte units per lane, in the order the
-//                          second launch reads them.
-//   upols_mac_kernel     : acc += pair_op_p(Z_{b-p}) for p = 0 .. P-1 - the matrix of a pair formed in the kernel from 16 bytes of
-//                          table per pair and partition ((2s, 2d) of H_p's two bins) and the bin's twiddle - then the inverse passes,
-//                          the kept half [B, 2B) converted / passed through a fused effect and stored.  The launch is bound by what
-//                          the L1 / L2 path delivers (tables + spectra: 16 P bytes per output sample - 8 of table, 8 of spectrum).
+//                          -> the real-FFT SPLIT of the thread's registers (both partners of a bin pair live in one thread) -> the
+//                          delay line.  What is stored is the half spectrum of the block's 2B real samples - A = 2 X[k] in the place
+//                          of Z[k], B = 2 conj X[M-k] in the place of Z[M-k] (upols_split) - in the REGISTER LAYOUT of the plan
+//                          (element e = tid + T m of the last forward pass), 8 M bytes per block, in 16-byte units per lane, in
+//                          the order the second launch reads them.
+//   upols_mac_kernel     : acc += g_p . S_{b-p} for p = 0 .. P-1, register by register - ONE complex multiply-add per register and
+//                          partition against a table in the same layout (H_p[k] / 4M, or its conjugate on the partners' places:
+//                          upols_upload_tables) - then the re-packing for the inverse (upols_merge, once per output block), the
+//                          inverse passes, the kept half [B, 2B) converted / passed through a fused effect and stored.  The launch
+//                          is bound by what the L1 / L2 path delivers (tables + spectra: 16 P bytes per output sample - 8 of table,
+//                          8 of spectrum), not by its arithmetic: rounds 5 - 6a multiplied the UNSPLIT Z by pair_op's 2x2 matrix per
+//                          pair and partition (22 vector instructions per pair against 8) and were 1 - 5 % slower per call
+//                          (profiles/r6f_upols_split_spectra_ab.txt).
 // The second launch reads what the first one wrote: the kernel boundary is the only synchronisation (no flags, no scopes).
 // Consecutive blocks of a channel share P - 1 spectra; blockIdx -> (channel, block) keeps them on one XCD (their L2).
 //
@@ -49,17 +51,22 @@ int rccl_broadcast(float* const* d_buf, const int* devs, const hipStream_t* stre
 int rccl_broadcast_rank(const char* unique_id, int rank, int world, int root, int dev, float* d_buf, size_t count, hipStream_t stream);
 }  // namespace adsp
 
-// tuning (tools/sessions/r5_session12.sh): stages of the multiply kernel requested ahead, and its workgroups per CU
+// tuning: stages of the multiply kernel requested ahead, and its workgroups per CU (32 points per thread; the 64-point plan keeps two and two).
+// Rounds 5 - 6a: four stages ahead in two workgroups per CU (181 registers); the split form needs 148 registers with two stages ahead, three
+// workgroups fit, and that is 2 - 5 % faster at blocks of 8192 (tools/sessions/r6_session30.sh; four stages ahead at three per CU spill: +45 %)
 #ifndef ADSP_UPOLS_AHEAD
-#define ADSP_UPOLS_AHEAD 4
+#define ADSP_UPOLS_AHEAD 2
 #endif
 #ifndef ADSP_UPOLS_MAC_WAVES
-#define ADSP_UPOLS_MAC_WAVES 2
+#define ADSP_UPOLS_MAC_WAVES 3
+#endif
+#ifndef ADSP_UPOLS_FWD_WAVES
+#define ADSP_UPOLS_FWD_WAVES 3
 #endif
 #ifndef ADSP_UPOLS_FWD_NT
 #define ADSP_UPOLS_FWD_NT 0
 #endif
-#ifndef ADSP_UPOLS_ABLATE  // tuning builds only (make tuning EXTRA=-DADSP_UPOLS_ABLATE=<mask>): 1 no table loads, 2 no spectrum loads, 4 table entries (c1, c2, c4) not formed
+#ifndef ADSP_UPOLS_ABLATE  // tuning builds only (make tuning EXTRA=-DADSP_UPOLS_ABLATE=<mask>): 1 no table loads, 2 no spectrum loads
 #define ADSP_UPOLS_ABLATE 0
 #endif
 #if ADSP_UPOLS_ABLATE != 0 && !defined(ADSP_TUNING_BUILD)
@@ -74,8 +81,7 @@ struct UpolsArgs {
     void* out;           // [n_steps][C][N]
     const void* zeros;   // N zero samples
     const float4* tw;    // pass twiddles of the plan
-    const float4* pair;  // [P] tables of the regular pairs: [R][T] float4 = (2s, 2d) of pair r of thread t (adsp_upols_create), pair_stride float4 each
-    const float2* pair0; // [P] tables of thread 0's self-paired butterflies, pair0_stride float2 each
+    const float4* pair;  // [P] tables in the delay line's layout: [R][T] float4 = g of the unit's two registers (upols_upload_tables), pair_stride float4 each
     float2* zline;       // [C][R][PTS/2][T] float4: the delay line of forward-transformed blocks (two registers per unit: upols_forward_kernel)
     int ring_pos, ring_slots, C, N, nh, n_steps;
     float inv_n;
@@ -86,7 +92,7 @@ struct UpolsArgs {
     int rel_first;       // forward: window start of the first block; mac: output time of the first block's first kept sample - relative to
                          // the first new input sample of the call (may be negative)
     int ncg;
-    int pair_stride, pair0_stride;
+    int pair_stride;
     int epi_op;
     float epi_p0, epi_p1, epi_p2;
     // the multiply launch's extra workgroups (blockIdx >= mac_grid, one per channel) keep the input's tail for the next call's windows
@@ -153,11 +159,115 @@ __device__ __forceinline__ bool upols_block(const UpolsArgs& a, int& c, int& blk
     return c < a.C;
 }
 
+
+// The real-FFT split and its inverse, on the register layout of the in-register pairing plans (round 6, second half).  Register NB r of
+// thread t > 0 holds Z[k], k = t + (M/R) r, and register NB (R-1-r) + 1 its partner Z[M-k].  With U = Za + conj Zb, D = Za - conj Zb and
+// wc = -i exp(-i pi k / M) (fftconv_core.inc: pair_op)
+//     A = U + wc D  (= 2 X[k]),   B = U - wc D  (= 2 conj X[M-k])
+// are what the delay line keeps in the two registers' places (upols_split, once per input block), the multiply launch accumulates
+//     SP = sum_p g1_p A_{b-p},  SQ = sum_p g2_p B_{b-p}          g1 = H_p[k] / 4M,  g2 = conj(H_p[M-k]) / 4M
+// - ONE complex multiply-add per register and partition against a table that has the registers' layout - and
+//     Zy[k] = E + O,  Zy[M-k] = conj(E - O),   E = SP + SQ,  O = conj(wc) (SP - SQ)
+// (upols_merge, once per output block) is what the inverse passes take: pair_op's matrix c1 = 2s + 2d Re wc, c2 = -2i d Im wc, c4 = 2s - 2d Re wc
+// factored into its three steps, of which only the middle one depends on the partition.  (Rounds 5 - 6a summed pair_op_p(Z_{b-p}) on the
+// unsplit Z: 22 vector instructions per pair and partition - 16 for the matrix, 6 to form it from (2s, 2d) and the twiddle - against 8 here.)
+// Thread 0's two butterflies (bins (M/R) r and M/2R + (M/R) r) pair with THEMSELVES: register NB r with NB (R-r), NB r + 1 with
+// NB (R-1-r) + 1; bin 0 keeps (A, B) - both real - as the two parts of its one register, bin M/2 (wc = -1: Zy = 4 g2 Z) keeps 4 Z.
+template <class PL>
+struct UpolsTwiddle {  // wc of the pairs: (cos, sin)(pi t / M) in two registers, (cos, sin)(pi r / R) and (pi (r + 1/2) / R) as literals
+    static constexpr int R = PL::RL;
+    float c0, s0;
+    __device__ __forceinline__ explicit UpolsTwiddle(int tid) { sincospif(static_cast<float>(tid) / static_cast<float>(PL::M), &s0, &c0); }
+    __device__ __forceinline__ void regular(int r, float& wr, float& wi) const {  // k = tid + (M/R) r
+        constexpr HalfTurn<R> turn = half_turn<R>();
+        const float cr = turn.c[r], sr = turn.s[r];
+        wr = -fmaf(c0, sr, s0 * cr);  // -sin, -cos of pi k / M
+        wi = -fmaf(c0, cr, -s0 * sr);
+    }
+    static __device__ __forceinline__ void self_even(int r, float& wr, float& wi) {  // thread 0, k = (M/R) r
+        constexpr HalfTurn<2 * R> turn = half_turn<2 * R>();
+        wr = -turn.s[2 * r];
+        wi = -turn.c[2 * r];
+    }
+    static __device__ __forceinline__ void self_odd(int r, float& wr, float& wi) {  // thread 0, k = M/2R + (M/R) r
+        constexpr HalfTurn<2 * R> turn = half_turn<2 * R>();
+        wr = -turn.s[2 * r + 1];
+        wi = -turn.c[2 * r + 1];
+    }
+};
+
+__device__ __forceinline__ void upols_split_pair(float& zar, float& zai, float& zbr, float& zbi, float wr, float wi) {
+    const float ur = zar + zbr, ui = zai - zbi, dr = zar - zbr, di = zai + zbi;
+    const float tr = fmaf(wr, dr, -wi * di), ti = fmaf(wr, di, wi * dr);
+    zar = ur + tr;
+    zai = ui + ti;
+    zbr = ur - tr;
+    zbi = ui - ti;
+}
+__device__ __forceinline__ void upols_merge_pair(float& par, float& pai, float& qbr, float& qbi, float wr, float wi) {
+    const float er = par + qbr, ei = pai + qbi, fr = par - qbr, fi = pai - qbi;
+    const float orr = fmaf(wr, fr, wi * fi), oi = fmaf(wr, fi, -wi * fr);  // conj(wc) F
+    par = er + orr;
+    pai = ei + oi;
+    qbr = er - orr;
+    qbi = oi - ei;
+}
+
+template <class PL, class F0, class F1>
+__device__ __forceinline__ void upols_over_pairs(float (&xr)[PL::P], float (&xi)[PL::P], int tid, F0 pair_fn, F1 bin0_fn) {
+    constexpr int R = PL::RL, NB = PL::NBL;
+    const UpolsTwiddle<PL> tw(tid);
+    float wr, wi;
+    if (tid != 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            tw.regular(r, wr, wi);
+            pair_fn(xr[NB * r], xi[NB * r], xr[NB * (R - 1 - r) + 1], xi[NB * (R - 1 - r) + 1], wr, wi);
+        }
+    } else {
+        bin0_fn(xr[0], xi[0], xr[NB * (R / 2)], xi[NB * (R / 2)]);
+#pragma unroll
+        for (int r = 1; r < R / 2; ++r) {
+            UpolsTwiddle<PL>::self_even(r, wr, wi);
+            pair_fn(xr[NB * r], xi[NB * r], xr[NB * (R - r)], xi[NB * (R - r)], wr, wi);
+        }
+#pragma unroll
+        for (int r = 0; r < R / 2; ++r) {
+            UpolsTwiddle<PL>::self_odd(r, wr, wi);
+            pair_fn(xr[NB * r + 1], xi[NB * r + 1], xr[NB * (R - 1 - r) + 1], xi[NB * (R - 1 - r) + 1], wr, wi);
+        }
+    }
+}
+
+template <class PL>
+__device__ __forceinline__ void upols_split(float (&xr)[PL::P], float (&xi)[PL::P], int tid) {
+    upols_over_pairs<PL>(
+        xr, xi, tid, [](float& ar, float& ai, float& br, float& bi, float wr, float wi) { upols_split_pair(ar, ai, br, bi, wr, wi); },
+        [](float& z0r, float& z0i, float& zhr, float& zhi) {  // bins 0 and M/2 of thread 0
+            const float a = z0r, b = z0i;
+            z0r = 2.f * (a + b);  // A = 2 X[0]
+            z0i = 2.f * (a - b);  // B = 2 X[M]
+            zhr *= 4.f;
+            zhi *= 4.f;
+        });
+}
+
+// `s0`, `s1`: thread 0's sums for bin 0 (real table entries against the real A and B: the parts multiply one by one, not as complex numbers)
+template <class PL>
+__device__ __forceinline__ void upols_merge(float (&xr)[PL::P], float (&xi)[PL::P], int tid, float s0, float s1) {
+    upols_over_pairs<PL>(
+        xr, xi, tid, [](float& ar, float& ai, float& br, float& bi, float wr, float wi) { upols_merge_pair(ar, ai, br, bi, wr, wi); },
+        [s0, s1](float& z0r, float& z0i, float&, float&) {  // Zy[0] = (SP + SQ) + i (SP - SQ); bin M/2 is its sum as it stands
+            z0r = s0 + s1;
+            z0i = s0 - s1;
+        });
+}
+
 }  // namespace
 
 // ---- launch 1: window -> forward passes -> delay line ----------------------------------------------------------------
 template <class PL, bool S16>
-__global__ __launch_bounds__(PL::T, PL::P > 32 ? 2 : (PL::T > 256 ? 4 : 3)) void upols_forward_kernel(const UpolsArgs a) {
+__global__ __launch_bounds__(PL::T, PL::P > 32 ? 2 : (PL::T > 256 ? 4 : ADSP_UPOLS_FWD_WAVES)) void upols_forward_kernel(const UpolsArgs a) {
     constexpr int P = PL::P, T = PL::T;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     real2* lds = reinterpret_cast<real2*>(smem_raw);
@@ -232,11 +342,13 @@ __global__ __launch_bounds__(PL::T, PL::P > 32 ? 2 : (PL::T > 256 ? 4 : 3)) void
     upols_indices<PL>(tid, ja, jb);
     run_passes<PL, false, 0, const real4* __restrict__, (PL::P > 32 ? 1 : -1)>(xr, xi, lds, a.tw, tid, ja, jb);  // (64 points per thread: a laundered lane index per exchange, +10 % here - fftconv_core.inc: lane_mode)
 
+    constexpr int RR = PL::RL, NB = PL::NBL;
+    upols_split<PL>(xr, xi, tid);
+
     int slot = a.slot_first + blk;
     slot -= slot >= a.R ? a.R : 0;
     // the delay line holds a block as the multiply kernel reads it: 16 bytes per lane and load - unit 2h = the registers (NB 2h, NB (2h+1))
     // of the paired butterflies' first sides, unit 2h+1 = their partners (NB (R-1-2h) + 1, NB (R-2-2h) + 1); read back by the next launch (L2)
-    constexpr int RR = PL::RL, NB = PL::NBL;
     float4* z = reinterpret_cast<float4*>(a.zline) + (static_cast<size_t>(c) * a.R + slot) * (static_cast<size_t>(P / 2) * T) + tid;
 #pragma unroll
     for (int h = 0; h < RR / 2; ++h) {
@@ -275,9 +387,9 @@ __device__ __forceinline__ void upols_keep_tail(const UpolsArgs& a) {
     }
 }
 
-// ---- launch 2: sum over partitions of pair_op_p(Z_{b-p}) -> inverse passes -> kept half ----------------------------------
+// ---- launch 2: sum over partitions of g_p . S_{b-p} -> re-packing -> inverse passes -> kept half ----------------------------------
 template <class PL, bool S16>
-__global__ __launch_bounds__(PL::T, ADSP_UPOLS_MAC_WAVES) void upols_mac_kernel(const UpolsArgs a) {
+__global__ __launch_bounds__(PL::T, PL::P > 32 ? 2 : ADSP_UPOLS_MAC_WAVES) void upols_mac_kernel(const UpolsArgs a) {
     constexpr int P = PL::P, T = PL::T, R = PL::RL, NB = PL::NBL;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     real2* lds = reinterpret_cast<real2*>(smem_raw);
@@ -301,45 +413,13 @@ __global__ __launch_bounds__(PL::T, ADSP_UPOLS_MAC_WAVES) void upols_mac_kernel(
         return zc + static_cast<size_t>(slot) * kSlot;
     };
 
-    // Thread 0's self-paired butterflies j = 0 (registers NB r) and j = M/R/2 (NB r + 1): 17 pairs, entries as in spectrum_stage.
-    // Lane e of the first wave takes pair e through all partitions; the sums wait for thread 0 in the (still idle) exchange buffer.
-    // First, while the accumulators are not live yet.
-    constexpr int kSelf = 2 + (R / 2 - 1) + R / 2;
-    if (tid < kSelf) {
-        int ia, ib;
-        if (tid == 0) ia = ib = 0;
-        else if (tid == 1) ia = ib = NB * (R / 2);
-        else if (tid < 2 + (R / 2 - 1)) ia = NB * (tid - 1), ib = NB * (R - (tid - 1));
-        else ia = NB * (tid - (2 + R / 2 - 1)) + 1, ib = NB * (R - 1 - (tid - (2 + R / 2 - 1))) + 1;
-        auto where = [&](int m) {  // register m of thread 0 in a block of the delay line (float2 units): see upols_forward_kernel
-            const bool partner = m & 1;
-            const int q = partner ? R - 1 - m / NB : m / NB;
-            return ((q & ~1) + (partner ? 1 : 0)) * T * 2 + (q & 1);
-        };
-        float sar = 0.f, sai = 0.f, sbr = 0.f, sbi = 0.f;
-#pragma unroll 4
-        for (int p = 0; p < a.P; ++p) {
-            const float2* z = block_of(p);
-            const float2* tab0 = a.pair0 + static_cast<size_t>(p) * a.pair0_stride + tid * 3;
-            const float2 va = z[where(ia)], vb = z[where(ib)];  // (ia == ib: the bin pairs with itself)
-            float zar = va.x, zai = va.y, zbr = vb.x, zbi = vb.y;
-            pair_op(zar, zai, zbr, zbi, tab0[0], tab0[1], tab0[2]);
-            sar += zar;
-            sai += zai;
-            sbr += zbr;
-            sbi += zbi;
-        }
-        lds[ib] = make_float2(sbr, sbi);
-        lds[ia] = make_float2(sar, sai);  // (second: a self-paired bin keeps its first output)
-    }
-
-    // Every lane runs the regular pairing (register NB r of butterfly tid with register NB (R-1-r) + 1 of its mirror) as one
-    // stream of stages - a stage is two pairs: three float4 of table, four float2 of spectrum - with kAhead stages requested
-    // ahead of the one being multiplied, across partition boundaries.  Lane 0's butterflies pair with THEMSELVES: what it
-    // accumulates here is replaced by the sums above.
+    // One stream of stages - a stage is four registers: two float4 of table, two float4 of spectrum, in the delay line's units (2h: registers
+    // NB 2h and NB (2h+1), 2h + 1: NB (R-1-2h) + 1 and NB (R-2-2h) + 1) - with kAhead stages requested ahead of the one being multiplied,
+    // across partition boundaries.  Every register is one complex multiply-add per partition (upols_split's header); lane 0's register 0
+    // - bin 0, whose two parts are the real A and B - is summed a second time part by part (sp0, sp1: every lane does, lane 0 uses it).
     struct Stage {
-        float4 t0, t1;  // (2s, 2d) of the stage's two pairs: s = g1 + g2, d = g1 - g2 of pair_op's matrix (fftconv_core.inc), 16 bytes per pair
-        float4 za, zb;  // (register NB 2h, register NB (2h+1)) and their partners: the delay line's units 2h, 2h+1
+        float4 t0, t1;  // g of the stage's four registers: H_p[k] / 4M on first sides, conj(H_p[M-k]) / 4M on their partners (upols_upload_tables)
+        float4 za, zb;  // the delay line's units 2h, 2h+1
     };
     constexpr int kStages = R / 2, kAhead = PL::P > 32 ? 2 : ADSP_UPOLS_AHEAD;  // (64 points per thread: 128 accumulators leave room for two stages)
     static_assert(kStages % kAhead == 0, "the stage ring is indexed at compile time");
@@ -365,31 +445,20 @@ __global__ __launch_bounds__(PL::T, ADSP_UPOLS_MAC_WAVES) void upols_mac_kernel(
         s.zb = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rz, lane16, (2 * h + 1) * T * 16, 0));
 #endif
     };
-    // The matrix entries c1 = 2s + 2d Re(wc), c2 = -2i d Im(wc), c4 = 2s - 2d Re(wc) are formed here: the twiddle wc = -i exp(-i pi k / M) of
-    // bin k = tid + (M / R) r does not depend on the partition - (cos, sin)(pi tid / M) in two registers, (cos, sin)(pi r / R) literals - so the
-    // tables carry 16 instead of 24 bytes per pair and partition (the launch is bound by what the L2 delivers, not by the 10 instructions).
-    float c0, s0;
-    sincospif(static_cast<float>(tid) / static_cast<float>(PL::M), &s0, &c0);
-    // pair_op with the accumulation folded into its multiply-adds (16 instead of 20 instructions per pair)
-    auto pair_mac = [](float& xar, float& xai, float& xbr, float& xbi, float zar, float zai, float zbr, float zbi, const float2 c1, const float2 c2,
-                       const float2 c4) {
-        xar = fmaf(c2.y, zbi, fmaf(c2.x, zbr, fmaf(-c1.y, zai, fmaf(c1.x, zar, xar))));
-        xai = fmaf(-c2.x, zbi, fmaf(c2.y, zbr, fmaf(c1.y, zar, fmaf(c1.x, zai, xai))));
-        xbr = fmaf(c2.y, zai, fmaf(-c2.x, zar, fmaf(c4.y, zbi, fmaf(c4.x, zbr, xbr))));
-        xbi = fmaf(c2.y, zar, fmaf(c2.x, zai, fmaf(c4.x, zbi, fmaf(-c4.y, zbr, xbi))));
-    };
-    auto pair_of = [&](int r, const float4 sd, float zar, float zai, float zbr, float zbi) {
-        constexpr HalfTurn<R> turn = half_turn<R>();
-        const float cr = turn.c[r], sr = turn.s[r];
-        const float wr = -fmaf(c0, sr, s0 * cr), wi = -fmaf(c0, cr, -s0 * sr);  // -sin, -cos of pi k / M
-        const float2 c1 = make_float2(fmaf(sd.z, wr, sd.x), fmaf(sd.w, wr, sd.y));
-        const float2 c4 = make_float2(fmaf(-sd.z, wr, sd.x), fmaf(-sd.w, wr, sd.y));
-        const float2 c2 = make_float2(sd.w * wi, -sd.z * wi);
-        pair_mac(ar[NB * r], ai[NB * r], ar[NB * (R - 1 - r) + 1], ai[NB * (R - 1 - r) + 1], zar, zai, zbr, zbi, c1, c2, c4);
+    float sp0 = 0.f, sp1 = 0.f;
+    auto cmac = [](float& xr_, float& xi_, float gr, float gi, float zr, float zi) {
+        xr_ = fmaf(-gi, zi, fmaf(gr, zr, xr_));
+        xi_ = fmaf(gi, zr, fmaf(gr, zi, xi_));
     };
     auto multiply = [&](const Stage& s, int h) {
-        pair_of(2 * h, s.t0, s.za.x, s.za.y, s.zb.x, s.zb.y);
-        pair_of(2 * h + 1, s.t1, s.za.z, s.za.w, s.zb.z, s.zb.w);
+        if (h == 0) {
+            sp0 = fmaf(s.t0.x, s.za.x, sp0);
+            sp1 = fmaf(s.t0.y, s.za.y, sp1);
+        }
+        cmac(ar[NB * (2 * h)], ai[NB * (2 * h)], s.t0.x, s.t0.y, s.za.x, s.za.y);
+        cmac(ar[NB * (2 * h + 1)], ai[NB * (2 * h + 1)], s.t0.z, s.t0.w, s.za.z, s.za.w);
+        cmac(ar[NB * (R - 1 - 2 * h) + 1], ai[NB * (R - 1 - 2 * h) + 1], s.t1.x, s.t1.y, s.zb.x, s.zb.y);
+        cmac(ar[NB * (R - 2 - 2 * h) + 1], ai[NB * (R - 2 - 2 * h) + 1], s.t1.z, s.t1.w, s.zb.z, s.zb.w);
     };
     {
         // Partition order: block b starts with partition b mod P and wraps around, so that the workgroups of a channel's consecutive
@@ -422,15 +491,7 @@ __global__ __launch_bounds__(PL::T, ADSP_UPOLS_MAC_WAVES) void upols_mac_kernel(
         partition(std::false_type{}, z, tab);
     }
 
-    __syncthreads();
-    if (tid == 0) {
-#pragma unroll
-        for (int m = 0; m < P; ++m) {
-            const real2 v = lds[m];
-            ar[m] = v.x;
-            ai[m] = v.y;
-        }
-    }
+    upols_merge<PL>(ar, ai, tid, sp0, sp1);
     int ja, jb;
     upols_indices<PL>(tid, ja, jb);
     run_passes<PL, true, 0, const real4* __restrict__, (PL::P > 32 ? 1 : -1)>(ai, ar, lds, a.tw, tid, ja, jb);  // inverse = forward on swapped parts
@@ -566,9 +627,8 @@ struct adsp_upols {
     char* zeros;
     float4* tw;
     float4* pair;
-    float2* pair0;
     float2* zline;
-    int pair_stride, pair0_stride;
+    int pair_stride;
     int epi_op;
     float epi_p[3];
     int lfo_len;             // fused tremolo: LFO table length and the length of the reference's LFO buffer (EffectTremolo.py:40-45): the
@@ -631,7 +691,6 @@ int upols_launch_pair(adsp_upols* u, const void* d_in, void* d_out, int n, hipSt
     a.zeros = u->zeros;
     a.tw = u->tw;
     a.pair = u->pair;
-    a.pair0 = u->pair0;
     a.zline = u->zline;
     a.ring_pos = u->ring_pos;
     a.ring_slots = u->ring_slots;
@@ -644,7 +703,6 @@ int upols_launch_pair(adsp_upols* u, const void* d_in, void* d_out, int n, hipSt
     a.R = u->R;
     a.ncg = c.n_channels;
     a.pair_stride = u->pair_stride;
-    a.pair0_stride = u->pair0_stride;
     a.epi_op = u->epi_op;
     a.epi_p0 = u->epi_p[0];
     a.epi_p1 = u->epi_p[1];
@@ -693,39 +751,49 @@ namespace {
 size_t upols_spectra_floats(const adsp_upols* u) { return (size_t)u->cfg.n_partitions * 2 * ((size_t)u->plan->block + 1); }
 
 // Host spectra -> the multiply launch's tables (allocated on first use; later calls - adsp_upols_set_spectra, a broadcast - overwrite
-// them: the caller has drained the device).  Per partition: tab0 = the (c1, c2, c4) entries of thread 0's self-paired butterflies, built
-// like an engine's (build_pair_tables); the regular pairs as (2s, 2d) - pair r of thread t is the bins k = t + (M / R) r and M - k
-// (table_build.hpp: pair_entry):  g1 = H[k] / 4M, g2 = conj(H[M-k]) / 4M, s = g1 + g2, d = g1 - g2;  the kernel forms c1, c2, c4 from
-// them and the bin's twiddle.
+// them: the caller has drained the device).  Per partition one table in the delay line's layout, [R][T] float4: unit 2h = the registers
+// (NB 2h, NB (2h+1)) of thread t, unit 2h + 1 = (NB (R-1-2h) + 1, NB (R-2-2h) + 1).  Register NB r + i holds bin j_i + (M/R) r of the
+// butterfly j_0 = t, j_1 = M/R - t (thread 0: 0 and M/2R); a register that is the FIRST side of its pair carries g1 = H[bin] / 4M, a
+// partner g2 = conj(H[bin]) / 4M (upols_split's header).  Thread 0's butterflies pair with themselves: their upper halves are the
+// partners; bin M/2 pairs with itself and carries g2; bin 0's register holds the real (A, B) and carries (H[0], H[M]) / 4M as its two
+// parts - the imaginary parts of the kernel's bins 0 and M are zero (a real kernel) and are not looked at.
 int upols_upload_tables(adsp_upols* u, const float* spectra) {
     const adsp_upols_config* cfg = &u->cfg;
     const PlanInfo pl = u->plan->shape;
     const int kB = u->plan->block;
-    std::vector<float4> tab, all;
-    std::vector<float2> tab0, all0;
-    const int RR = pl.rad[pl.NP - 1], D = kB / RR, T = pl.T;
-    if (pl.XL || pl.P / RR != 2) return fail(ADSP_ERR_STATE, "internal: the partitioned engines run in-register pairing plans with one pair of butterflies per thread");
+    std::vector<float4> all;
+    const int RR = pl.rad[pl.NP - 1], D = kB / RR, T = pl.T, NB = pl.P / RR;
+    if (pl.XL || NB != 2) return fail(ADSP_ERR_STATE, "internal: the partitioned engines run in-register pairing plans with one pair of butterflies per thread");
     u->pair_stride = RR * T;
     all.resize((size_t)cfg->n_partitions * u->pair_stride);
+    const double sc = 1.0 / (4.0 * (double)kB);
     for (int p = 0; p < cfg->n_partitions; ++p) {
         const float* H = spectra + (size_t)p * 2 * (kB + 1);
-        build_pair_tables<float, float>(pl, kB, H, false, tab, tab0);
-        if (p == 0) u->pair0_stride = (int)tab0.size();
-        all0.insert(all0.end(), tab0.begin(), tab0.end());
-        const double sc = 1.0 / (4.0 * (double)kB);
-        for (int r = 0; r < RR; ++r)
+        auto entry = [&](int t, int m, float& gr, float& gi) {  // register m of thread t
+            const int i = m % NB, r = m / NB;
+            const int bin = (i == 0 ? t : (t == 0 ? D / 2 : D - t)) + D * r;
+            const bool partner = t == 0 ? r >= RR / 2 : i == 1;
+            if (t == 0 && m == 0) {
+                gr = (float)((double)H[0] * sc);
+                gi = (float)((double)H[2 * kB] * sc);
+                return;
+            }
+            gr = (float)((double)H[2 * bin] * sc);
+            gi = (float)((partner ? -1.0 : 1.0) * (double)H[2 * bin + 1] * sc);
+        };
+        for (int h = 0; h < RR / 2; ++h)
             for (int t = 0; t < T; ++t) {
-                const int k = t + D * r;
-                const double g1r = (double)H[2 * k] * sc, g1i = (double)H[2 * k + 1] * sc;
-                const double g2r = (double)H[2 * (kB - k)] * sc, g2i = -(double)H[2 * (kB - k) + 1] * sc;
-                all[(size_t)p * u->pair_stride + (size_t)r * T + t] =
-                    make_float4((float)(2.0 * (g1r + g2r)), (float)(2.0 * (g1i + g2i)), (float)(2.0 * (g1r - g2r)), (float)(2.0 * (g1i - g2i)));
+                float4 a, b;
+                entry(t, NB * (2 * h), a.x, a.y);
+                entry(t, NB * (2 * h + 1), a.z, a.w);
+                entry(t, NB * (RR - 1 - 2 * h) + 1, b.x, b.y);
+                entry(t, NB * (RR - 2 - 2 * h) + 1, b.z, b.w);
+                all[(size_t)p * u->pair_stride + (size_t)(2 * h) * T + t] = a;
+                all[(size_t)p * u->pair_stride + (size_t)(2 * h + 1) * T + t] = b;
             }
     }
     if (!u->pair) HIP_TRY(hipMalloc(&u->pair, all.size() * sizeof(float4)));
-    if (!u->pair0) HIP_TRY(hipMalloc(&u->pair0, all0.size() * sizeof(float2)));
     HIP_TRY(hipMemcpy(u->pair, all.data(), all.size() * sizeof(float4), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(u->pair0, all0.data(), all0.size() * sizeof(float2), hipMemcpyHostToDevice));
     if (!u->spectra) u->spectra = new std::vector<float>();
     u->spectra->assign(spectra, spectra + upols_spectra_floats(u));
     return ADSP_OK;
@@ -819,7 +887,7 @@ void adsp_upols_destroy(adsp_upols* u) {
     if (!u) return;
     (void)hipSetDevice(u->cfg.device_id);
     (void)hipDeviceSynchronize();
-    for (void* p : {(void*)u->ring, (void*)u->zeros, (void*)u->tw, (void*)u->pair, (void*)u->pair0, (void*)u->zline, (void*)u->stage_in, (void*)u->stage_out})
+    for (void* p : {(void*)u->ring, (void*)u->zeros, (void*)u->tw, (void*)u->pair, (void*)u->zline, (void*)u->stage_in, (void*)u->stage_out})
         if (p) (void)hipFree(p);
     if (u->ev_done) (void)hipEventDestroy(u->ev_done);
     if (u->d_spectra) (void)hipFree(u->d_spectra);
