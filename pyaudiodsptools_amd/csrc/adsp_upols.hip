@@ -974,7 +974,7 @@ struct UpolsStateHeader {
     long long steps_done, fwd_done, lfo_copy_len;
     unsigned long long ring_bytes, zline_bytes;
 };
-constexpr unsigned kStateMagic = 0x55504f4cu;  // "UPOL"
+constexpr unsigned kStateMagic = 0x55504f32u;  // "UPO2": the delay line holds split half spectra ("UPOL" = 0x55504f4c: the unsplit Z of the builds before)
 }  // namespace
 
 int adsp_upols_state_bytes(const adsp_upols* u, size_t* bytes) {
@@ -1015,6 +1015,7 @@ int adsp_upols_set_state(adsp_upols* u, const void* state, size_t bytes) {
     UpolsStateHeader h;
     if (bytes < sizeof h) return fail(ADSP_ERR_ARG, "state of %zu bytes is shorter than its header", bytes);
     memcpy(&h, state, sizeof h);
+    if (h.magic == 0x55504f4cu) return fail(ADSP_ERR_ARG, "the state was taken by an earlier build, whose delay line kept unsplit spectra: it cannot be resumed here");
     if (h.magic != kStateMagic) return fail(ADSP_ERR_ARG, "not a state of a partitioned engine (magic %08x)", h.magic);
     const adsp_upols_config& c = u->cfg;
     if (h.cfg.chunk_size != c.chunk_size || h.cfg.n_channels != c.n_channels || h.cfg.block_size != c.block_size ||

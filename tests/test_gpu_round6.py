@@ -232,6 +232,10 @@ def test_upols_state_roundtrip_reset_and_refusals(adsp, block):
     bad[0] ^= 0xFF
     with pytest.raises(adsp.AdspError):
         c.set_state(bad)
+    old_build = state.copy()  # a checkpoint of the builds whose delay line kept UNSPLIT spectra (magic "UPOL"): refused by name
+    old_build[:4] = np.frombuffer(np.uint32(0x55504F4C).tobytes(), np.uint8)
+    with pytest.raises(adsp.AdspError, match="unsplit"):
+        c.set_state(old_build)
     for e in (a, b, c, other):
         e.close()
 
