@@ -213,36 +213,59 @@ __device__ __forceinline__ void upols_merge_pair(float& par, float& pai, float& 
     qbi = oi - ei;
 }
 
+// Thread 0's own pairing must not be the other side of an if / else over the 2 P registers: the register allocator keeps what a divergent
+// `else` reads alive across the `then` (the compiler's view of a wave is not per lane), which doubles the registers' live ranges (+64: the
+// launches spilled, and the 8192-point multiply launch needed 148 registers).  Instead thread 0 parks its registers in `park` (2 P floats of
+// LDS behind the exchange buffer), every lane runs the regular pairing - thread 0 on values it will not use - and thread 0 then pairs its
+// parked values its own way into the same registers.
 template <class PL, class F0, class F1>
-__device__ __forceinline__ void upols_over_pairs(float (&xr)[PL::P], float (&xi)[PL::P], int tid, F0 pair_fn, F1 bin0_fn) {
+__device__ __forceinline__ void upols_over_pairs(float (&xr)[PL::P], float (&xi)[PL::P], int tid, float2* park, F0 pair_fn, F1 bin0_fn) {
     constexpr int R = PL::RL, NB = PL::NBL;
+    if (tid == 0) {
+#pragma unroll
+        for (int m = 0; m < PL::P; ++m) park[m] = make_float2(xr[m], xi[m]);
+    }
     const UpolsTwiddle<PL> tw(tid);
     float wr, wi;
-    if (tid != 0) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            tw.regular(r, wr, wi);
-            pair_fn(xr[NB * r], xi[NB * r], xr[NB * (R - 1 - r) + 1], xi[NB * (R - 1 - r) + 1], wr, wi);
+    for (int r = 0; r < R; ++r) {
+        tw.regular(r, wr, wi);
+        pair_fn(xr[NB * r], xi[NB * r], xr[NB * (R - 1 - r) + 1], xi[NB * (R - 1 - r) + 1], wr, wi);
+    }
+    if (tid == 0) {
+        auto pair_at = [&](int ma, int mb) {
+            float2 a = park[ma], b = park[mb];
+            pair_fn(a.x, a.y, b.x, b.y, wr, wi);
+            xr[ma] = a.x;
+            xi[ma] = a.y;
+            xr[mb] = b.x;
+            xi[mb] = b.y;
+        };
+        {
+            float2 z0 = park[0], zh = park[NB * (R / 2)];
+            bin0_fn(z0.x, z0.y, zh.x, zh.y);
+            xr[0] = z0.x;
+            xi[0] = z0.y;
+            xr[NB * (R / 2)] = zh.x;
+            xi[NB * (R / 2)] = zh.y;
         }
-    } else {
-        bin0_fn(xr[0], xi[0], xr[NB * (R / 2)], xi[NB * (R / 2)]);
 #pragma unroll
         for (int r = 1; r < R / 2; ++r) {
             UpolsTwiddle<PL>::self_even(r, wr, wi);
-            pair_fn(xr[NB * r], xi[NB * r], xr[NB * (R - r)], xi[NB * (R - r)], wr, wi);
+            pair_at(NB * r, NB * (R - r));
         }
 #pragma unroll
         for (int r = 0; r < R / 2; ++r) {
             UpolsTwiddle<PL>::self_odd(r, wr, wi);
-            pair_fn(xr[NB * r + 1], xi[NB * r + 1], xr[NB * (R - 1 - r) + 1], xi[NB * (R - 1 - r) + 1], wr, wi);
+            pair_at(NB * r + 1, NB * (R - 1 - r) + 1);
         }
     }
 }
 
 template <class PL>
-__device__ __forceinline__ void upols_split(float (&xr)[PL::P], float (&xi)[PL::P], int tid) {
+__device__ __forceinline__ void upols_split(float (&xr)[PL::P], float (&xi)[PL::P], int tid, float2* park) {
     upols_over_pairs<PL>(
-        xr, xi, tid, [](float& ar, float& ai, float& br, float& bi, float wr, float wi) { upols_split_pair(ar, ai, br, bi, wr, wi); },
+        xr, xi, tid, park, [](float& ar, float& ai, float& br, float& bi, float wr, float wi) { upols_split_pair(ar, ai, br, bi, wr, wi); },
         [](float& z0r, float& z0i, float& zhr, float& zhi) {  // bins 0 and M/2 of thread 0
             const float a = z0r, b = z0i;
             z0r = 2.f * (a + b);  // A = 2 X[0]
@@ -254,9 +277,9 @@ __device__ __forceinline__ void upols_split(float (&xr)[PL::P], float (&xi)[PL::
 
 // `s0`, `s1`: thread 0's sums for bin 0 (real table entries against the real A and B: the parts multiply one by one, not as complex numbers)
 template <class PL>
-__device__ __forceinline__ void upols_merge(float (&xr)[PL::P], float (&xi)[PL::P], int tid, float s0, float s1) {
+__device__ __forceinline__ void upols_merge(float (&xr)[PL::P], float (&xi)[PL::P], int tid, float2* park, float s0, float s1) {
     upols_over_pairs<PL>(
-        xr, xi, tid, [](float& ar, float& ai, float& br, float& bi, float wr, float wi) { upols_merge_pair(ar, ai, br, bi, wr, wi); },
+        xr, xi, tid, park, [](float& ar, float& ai, float& br, float& bi, float wr, float wi) { upols_merge_pair(ar, ai, br, bi, wr, wi); },
         [s0, s1](float& z0r, float& z0i, float&, float&) {  // Zy[0] = (SP + SQ) + i (SP - SQ); bin M/2 is its sum as it stands
             z0r = s0 + s1;
             z0i = s0 - s1;
@@ -343,7 +366,9 @@ __global__ __launch_bounds__(PL::T, PL::P > 32 ? 2 : (PL::T > 256 ? 4 : ADSP_UPO
     run_passes<PL, false, 0, const real4* __restrict__, (PL::P > 32 ? 1 : -1)>(xr, xi, lds, a.tw, tid, ja, jb);  // (64 points per thread: a laundered lane index per exchange, +10 % here - fftconv_core.inc: lane_mode)
 
     constexpr int RR = PL::RL, NB = PL::NBL;
-    upols_split<PL>(xr, xi, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    upols_split<PL>(xr, xi, tid, lds + PL::LDS_ELEMS);
+    __builtin_amdgcn_sched_barrier(0);
 
     int slot = a.slot_first + blk;
     slot -= slot >= a.R ? a.R : 0;
@@ -389,7 +414,7 @@ __device__ __forceinline__ void upols_keep_tail(const UpolsArgs& a) {
 
 // ---- launch 2: sum over partitions of g_p . S_{b-p} -> re-packing -> inverse passes -> kept half ----------------------------------
 template <class PL, bool S16>
-__global__ __launch_bounds__(PL::T, PL::P > 32 ? 2 : ADSP_UPOLS_MAC_WAVES) void upols_mac_kernel(const UpolsArgs a) {
+__global__ __launch_bounds__(PL::T, PL::P > 32 ? 2 : (PL::T > 256 ? 4 : ADSP_UPOLS_MAC_WAVES)) void upols_mac_kernel(const UpolsArgs a) {
     constexpr int P = PL::P, T = PL::T, R = PL::RL, NB = PL::NBL;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     real2* lds = reinterpret_cast<real2*>(smem_raw);
@@ -421,7 +446,8 @@ __global__ __launch_bounds__(PL::T, PL::P > 32 ? 2 : ADSP_UPOLS_MAC_WAVES) void 
         float4 t0, t1;  // g of the stage's four registers: H_p[k] / 4M on first sides, conj(H_p[M-k]) / 4M on their partners (upols_upload_tables)
         float4 za, zb;  // the delay line's units 2h, 2h+1
     };
-    constexpr int kStages = R / 2, kAhead = PL::P > 32 ? 2 : ADSP_UPOLS_AHEAD;  // (64 points per thread: 128 accumulators leave room for two stages)
+    // (64 points per thread: 128 accumulators leave room for two stages; 32 points in 512 threads - blocks of 16384 - must stay within 128 registers: one)
+    constexpr int kStages = R / 2, kAhead = PL::P > 32 ? 2 : (PL::T > 256 ? 1 : ADSP_UPOLS_AHEAD);
     static_assert(kStages % kAhead == 0, "the stage ring is indexed at compile time");
     Stage st[kAhead];
     // buffer loads of 16 bytes per lane (the vector-memory path takes ~7 ns per wave instruction whatever its width: micro/tcp_rate.hip):
@@ -491,7 +517,9 @@ __global__ __launch_bounds__(PL::T, PL::P > 32 ? 2 : ADSP_UPOLS_MAC_WAVES) void 
         partition(std::false_type{}, z, tab);
     }
 
-    upols_merge<PL>(ar, ai, tid, sp0, sp1);
+    __builtin_amdgcn_sched_barrier(0);  // (the inverse passes' address arithmetic and twiddle requests stay behind the re-packing: hoisted above it they spill)
+    upols_merge<PL>(ar, ai, tid, lds + PL::LDS_ELEMS, sp0, sp1);
+    __builtin_amdgcn_sched_barrier(0);
     int ja, jb;
     upols_indices<PL>(tid, ja, jb);
     run_passes<PL, true, 0, const real4* __restrict__, (PL::P > 32 ? 1 : -1)>(ai, ar, lds, a.tw, tid, ja, jb);  // inverse = forward on swapped parts
@@ -580,7 +608,7 @@ namespace {
 using namespace adsp;
 using namespace adsp::tables;
 // The block sizes of this build: B = 8192 on the 32-points-per-thread plan (32 KiB of LDS, three / two workgroups per CU) and
-// B = 16384 on the 64-points-per-thread plan (64 KiB, two workgroups per CU).  Per output sample the multiply launch reads
+// B = 16384 on 32 points per thread in 512 threads (64 KiB, two workgroups of eight waves per CU).  Per output sample the multiply launch reads
 // n_partitions x 16 bytes (8 of table, 8 of spectrum), and n_partitions = ceil(taps / B): the larger block halves what bounds the engine, for ~8 % more transform work.
 struct UpolsPlan {
     int block, threads, lds_bytes;
@@ -594,7 +622,7 @@ UpolsPlan upols_plan() {
     UpolsPlan p;
     p.block = PL::M;
     p.threads = PL::T;
-    p.lds_bytes = PL::LDS_ELEMS * (int)sizeof(float2);
+    p.lds_bytes = (PL::LDS_ELEMS + PL::P) * (int)sizeof(float2);  // the exchange buffer + thread 0's parked registers (upols_over_pairs)
     p.shape = PlanInfo{PL::M, 8, PL::P, PL::T, 1, PL::NP, PL::XL ? 1 : 0, {PL::fwd(0), PL::fwd(1), PL::fwd(2), PL::fwd(3)},
                        PL::tw_total, PL::LDS_ELEMS * (int)sizeof(float2), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     p.fwd[0] = reinterpret_cast<const void*>(&upols_forward_kernel<PL, false>);
@@ -604,11 +632,14 @@ UpolsPlan upols_plan() {
     return p;
 }
 
-// Blocks of 16384 stay on 64 points per thread in 256 threads here: as 32 points per thread in 512 threads (what the single-transform engines
-// run since round 6, plan_table.hpp) the multiply launch has room for four stages of requests instead of two, but a call took +11 % / +9 %
-// at 1024 channels (profiles/r6_upols_block_16384_512_threads.txt)
+// Blocks of 16384 run as 32 points per thread in 512 threads (what the single-transform engines run since round 6, plan_table.hpp), one stage of
+// requests ahead: 125 / 122 registers without scratch, four waves per SIMD.  Against 64 points per thread in 256 threads (two waves per SIMD, two
+// stages ahead; rounds 5 - 6a) a call takes -15 % / -9.5 % at 256 channels and -5 ... -7 % / -4.3 % at 1024 (profiles/r6f_upols_split_spectra_ab.txt,
+// session 35).  It had LOST 9 - 11 % there while the multiply launch still multiplied unsplit spectra (profiles/r6_upols_block_16384_512_threads.txt)
+// and it spilled until thread 0's pairing stopped being the other side of an if / else (upols_over_pairs).  -DADSP_UPOLS_PLAN_16384=ADSP_PLAN_16384_64PT
+// builds the earlier form.
 #ifndef ADSP_UPOLS_PLAN_16384
-#define ADSP_UPOLS_PLAN_16384 ADSP_PLAN_16384_64PT
+#define ADSP_UPOLS_PLAN_16384 ADSP_PLAN_16384
 #endif
 const UpolsPlan* upols_plans(int* count) {
     static const UpolsPlan plans[] = {upols_plan<ADSP_PLAN_8192>(), upols_plan<ADSP_UPOLS_PLAN_16384>()};

@@ -293,20 +293,21 @@ class UniformPartition:
 
 
 def choose_uniform_block(fir: "FirStream", channels: int, sizes=(8192, 16384)) -> int:
-    """Block size of a uniformly partitioned engine.  Per output sample the multiply launch reads taps / B x 16 bytes of tables and
-    8 of spectra, so a larger block pays for kernels of many partitions - where the stream's delay allows it (partition_uniform:
-    delay >= block) and a call has blocks enough to fill the chip several times over; more and shorter workgroups win everywhere
-    else.  Measured at chunk 88200, round 6 (rotated partition order, tail-only ring update: profiles/r6_upols_block_sizes.txt): at 1024
-    channels blocks of 16384 take the EQ composite (11 partitions of 8192) from 1250 to 1045 us per call and the low cut (6 partitions)
-    from 879 to 818; at 64 channels 76.0 -> 76.3 and 59.6 -> 63.8.  (Round 5, before those two changes, had the low cut 5 % slower on the
-    large block: profiles/r5_upols_block_16384.txt.)"""
+    """Block size of a uniformly partitioned engine.  Per output sample the multiply launch reads taps / B x 16 bytes (8 of tables,
+    8 of spectra), so a larger block pays for kernels of many partitions - where the stream's delay allows it (partition_uniform:
+    delay >= block) and a call has workgroups enough to occupy the chip; below that the call is as long as ONE workgroup's chain of
+    work, and the shorter workgroups of the small block win.  Measured at chunk 88200 (low cut: 6 partitions of 8192, EQ composite: 11)
+    since blocks of 16384 run on 512 threads (tools/sessions/r6_session36.sh, 37: profiles/r6f_upols_block_sizes.txt), us per call,
+    blocks of 8192 -> 16384:  16 channels 29.5 -> 33 / 35.6 -> 39.3;  32 channels 39.5 -> 35.8 / 50.3 -> 42.1;  64 channels 53.4 -> 52.0 /
+    70.5 -> 65.6;  256 channels 226 -> 193 / 319 -> 257;  1024 channels 806 -> 703 / 1150 -> 946.  (On 64 points per thread in 256
+    threads - rounds 5, 6a - the large block won from 256 channels on only: profiles/r6_upols_block_sizes.txt.)"""
     delay = int(fir.delay) - int(fir.delay) % 4
     valid = sorted(b for b in sizes if b <= delay)
     if not valid:
         return min(sizes)  # (partition_uniform raises for it)
     small, big = valid[0], valid[-1]
     many_partitions = -(-(len(fir.taps) + int(fir.delay) % 4) // small) >= 4
-    return big if many_partitions and int(channels) * int(fir.chunk_size) >= 1024 * big else small
+    return big if many_partitions and int(channels) * int(fir.chunk_size) >= 128 * big else small
 
 
 def partition_uniform(fir: FirStream, block: int, gain: float = 1.0) -> UniformPartition:

@@ -123,9 +123,9 @@ def test_block_size_policy():
     enough to fill the chip."""
     lc = design.FirStream(design.lowcut_kernel(800, 44100, 88200), 88200)                      # 6 partitions of 8192
     eq = design.FirStream(design.eq3_composite(100, 2, 700, -4, 8000, 5, 44100, 88200), 88200)  # 11
-    assert all(design.choose_uniform_block(lc, c) == 8192 for c in (1, 64)) and all(design.choose_uniform_block(lc, c) == 16384 for c in (256, 1024, 4096))
-    assert design.choose_uniform_block(eq, 1) == 8192 and design.choose_uniform_block(eq, 64) == 8192
-    assert design.choose_uniform_block(eq, 256) == 16384 and design.choose_uniform_block(eq, 4096) == 16384
+    assert all(design.choose_uniform_block(lc, c) == 8192 for c in (1, 16)) and all(design.choose_uniform_block(lc, c) == 16384 for c in (32, 64, 256, 1024, 4096))
+    assert design.choose_uniform_block(eq, 1) == 8192 and design.choose_uniform_block(eq, 16) == 8192
+    assert design.choose_uniform_block(eq, 32) == 16384 and design.choose_uniform_block(eq, 64) == 16384 and design.choose_uniform_block(eq, 4096) == 16384
     three = design.FirStream(np.ones(20000), 88200)                                             # 3 partitions of 8192: the small block everywhere
     assert all(design.choose_uniform_block(three, c) == 8192 for c in (64, 4096))
     short_delay = design.FirStream(np.ones(100000), 20000, latency_chunks=1, lookahead=8000)   # delayed by 12000 samples
