@@ -54,8 +54,14 @@ int rccl_broadcast_rank(const char* unique_id, int rank, int world, int root, in
 // tuning: stages of the multiply kernel requested ahead, and its workgroups per CU (32 points per thread; the 64-point plan keeps two and two).
 // Rounds 5 - 6a: four stages ahead in two workgroups per CU (181 registers); the split form needs 148 registers with two stages ahead, three
 // workgroups fit, and that is 2 - 5 % faster at blocks of 8192 (tools/sessions/r6_session30.sh; four stages ahead at three per CU spill: +45 %)
+// (The compiler hoists a stage's successor requests above its multiply-adds, so the loads need a register set of their own: 148 registers at two
+// stages ahead.  With a scheduling barrier between them two stages fit 122 registers and four fit 140 - and the time does not move, at either block
+// size, at 64 ... 1024 channels: session 38.  The launch is bound by the bytes it pulls through L2 and HBM, not by how far ahead it asks.)
 #ifndef ADSP_UPOLS_AHEAD
 #define ADSP_UPOLS_AHEAD 2
+#endif
+#ifndef ADSP_UPOLS_AHEAD_512
+#define ADSP_UPOLS_AHEAD_512 1
 #endif
 #ifndef ADSP_UPOLS_MAC_WAVES
 #define ADSP_UPOLS_MAC_WAVES 3
@@ -447,7 +453,7 @@ __global__ __launch_bounds__(PL::T, PL::P > 32 ? 2 : (PL::T > 256 ? 4 : ADSP_UPO
         float4 za, zb;  // the delay line's units 2h, 2h+1
     };
     // (64 points per thread: 128 accumulators leave room for two stages; 32 points in 512 threads - blocks of 16384 - must stay within 128 registers: one)
-    constexpr int kStages = R / 2, kAhead = PL::P > 32 ? 2 : (PL::T > 256 ? 1 : ADSP_UPOLS_AHEAD);
+    constexpr int kStages = R / 2, kAhead = PL::P > 32 ? 2 : (PL::T > 256 ? ADSP_UPOLS_AHEAD_512 : ADSP_UPOLS_AHEAD);
     static_assert(kStages % kAhead == 0, "the stage ring is indexed at compile time");
     Stage st[kAhead];
     // buffer loads of 16 bytes per lane (the vector-memory path takes ~7 ns per wave instruction whatever its width: micro/tcp_rate.hip):
