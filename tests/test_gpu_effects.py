@@ -316,6 +316,7 @@ def test_mix_signals_and_mix_bus(adsp, golden):
     bus = adsp.MixBus([d.engine for d in devs])
     d_ins = [torch.from_numpy(x.reshape(6, 1, n)).cuda() for x in xs]
     d_out = torch.full((6, 1, n), 7.0, device="cuda")  # stale contents must not leak into the sum
+    torch.cuda.synchronize()   # the fill runs on torch's default stream: finished before another stream writes into the buffer
     bus.apply_device(d_ins, d_out, 6)
     torch.cuda.synchronize()
     assert_parity(d_out.cpu().numpy().reshape(-1), want, what="mix bus, one launch per engine")

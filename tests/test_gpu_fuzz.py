@@ -73,6 +73,7 @@ def test_random_geometry_and_call_pattern_against_the_exact_engine(seed):
         eng.set_block_outputs(int(rng.integers(1, eng.geometry.max_block_outputs // g + 1)) * g)
     x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=torch.Generator(device="cuda").manual_seed(seed))
     y = torch.full_like(x, float("nan"))
+    torch.cuda.synchronize()   # the fill runs on torch's default stream: finished before another stream writes into the buffer
     s = torch.cuda.current_stream().cuda_stream
     hip = ctypes.CDLL("libamdhip64.so")
     hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
@@ -154,6 +155,7 @@ def test_random_fused_volume_and_accumulate_against_the_exact_engine(seed):
     gen = torch.Generator(device="cuda").manual_seed(seed)
     x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=gen)
     base = torch.empty_like(x).uniform_(-0.5, 0.5, generator=gen)
+    torch.cuda.synchronize()   # the fill runs on torch's default stream: finished before another stream writes into the buffer
     y = base.clone()
     s = torch.cuda.current_stream().cuda_stream
     k = 0
@@ -212,6 +214,7 @@ def test_random_unaligned_chunk_sizes_against_the_exact_engine(seed):
     gen = torch.Generator(device="cuda").manual_seed(seed)
     x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=gen)
     base = torch.empty_like(x).uniform_(-0.5, 0.5, generator=gen) if acc else torch.full_like(x, float("nan"))
+    torch.cuda.synchronize()   # the fill runs on torch's default stream: finished before another stream writes into the buffer
     y = base.clone()
     if acc:
         eng.set_accumulate(1)

@@ -290,6 +290,7 @@ def test_example4_chunk_size_partitioned(adsp, golden):
             eng.reset()
             xd = torch.from_numpy(x.reshape(3, 1, n)).cuda()
             yd = torch.full_like(xd, 7.0)  # every sample must be overwritten (partitioned: part 0 overwrites, the others accumulate)
+            torch.cuda.synchronize()   # the fill runs on torch's default stream: finished before another stream writes into the buffer
             s = torch.cuda.current_stream().cuda_stream
             eng.apply_device(xd[:2], yd[:2], 2, s)
             eng.apply_device(xd[2], yd[2], 1, s)
@@ -746,6 +747,7 @@ def test_two_stream_ring_pattern_with_a_real_producer(adsp, n, kind):
     assert eng.ring_slots >= eng.geometry.history_chunks + 2
     x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=torch.Generator(device="cuda").manual_seed(n))
     y = torch.full_like(x, float("nan"))
+    torch.cuda.synchronize()   # the fill runs on torch's default stream: finished before another stream writes into the buffer
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     torch.cuda.synchronize()
     hip = ctypes.CDLL("libamdhip64.so")

@@ -130,6 +130,7 @@ def test_two_stream_ring_steps_are_ordered_by_the_library_under_skew(adsp, n, ki
     eng = FirEngine(fir, channels=channels, ring_slots=hist + extra_slots)
     x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=torch.Generator(device="cuda").manual_seed(n + extra_slots))
     y = torch.full_like(x, float("nan"))
+    torch.cuda.synchronize()   # the fill runs on torch's default stream: finished before another stream writes into the buffer
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     torch.cuda.synchronize()
     hip = ctypes.CDLL("libamdhip64.so")
@@ -290,6 +291,7 @@ def test_resident_ring_launch_waits_for_a_producer_that_starts_later(adsp, n, ki
     steps = per * launches
     x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=torch.Generator(device="cuda").manual_seed(n))
     y = torch.full_like(x, float("nan"))
+    torch.cuda.synchronize()   # the fill runs on torch's default stream: finished before another stream writes into the buffer
     cons, prod = torch.cuda.Stream(), torch.cuda.Stream()
     torch.cuda.synchronize()
     copy = _copy_fn()
@@ -346,6 +348,7 @@ def test_resident_ring_launch_without_a_producer_times_out_instead_of_hanging(ad
     eng = FirEngine(fir, channels=channels, ring_slots=8)
     eng.ring_resident_timeout(40.0)
     y = torch.full((4, channels, n), float("nan"), device="cuda")
+    torch.cuda.synchronize()   # the fill runs on torch's default stream: finished before another stream writes into the buffer
     with pytest.raises(adsp._capi.AdspError):
         eng.apply_ring_resident(y, 7, None)  # more steps than ring_slots - history
     t0 = time.perf_counter()

@@ -65,6 +65,7 @@ def test_batch_geometry_at_the_timed_size_every_sample(adsp, config, channels, m
     x[0, 0, 4095] = 1.0   # channel 0: unit impulse on the last sample of chunk 0
     x[:, 1] = 0           # channel 1: silence
     y = torch.full_like(x, float("nan"))
+    torch.cuda.synchronize()   # the fill runs on torch's default stream: finished before another stream writes into the buffer
     s = torch.cuda.current_stream().cuda_stream
     eng.apply_device(x, y, steps, s)
     torch.cuda.synchronize()
@@ -106,6 +107,7 @@ def test_resident_launches_full_size_across_ring_laps(adsp):
     g = torch.Generator(device="cuda").manual_seed(99)
     x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=g)
     y = torch.full_like(x, float("nan"))
+    torch.cuda.synchronize()   # the fill runs on torch's default stream: finished before another stream writes into the buffer
     cons, prod = torch.cuda.Stream(), torch.cuda.Stream()
     torch.cuda.synchronize()
     copy = _copy_fn()
@@ -141,6 +143,7 @@ def test_resident_launch_table_outlives_eight_pending_launches(adsp):
     g = torch.Generator(device="cuda").manual_seed(7)
     x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=g)
     y = torch.full_like(x, float("nan"))
+    torch.cuda.synchronize()   # the fill runs on torch's default stream: finished before another stream writes into the buffer
     cons, prod = torch.cuda.Stream(), torch.cuda.Stream()
     # something slow at the head of the consumer stream: the resident launches queue up behind it
     slow_fir = FirStream(np.random.default_rng(0).standard_normal(4000) / 100, 4096)
@@ -292,12 +295,14 @@ def test_unaligned_chunk_sizes_batches_vs_exact_engine(adsp, n, kind, channels):
     for mode in ("stream", "batch"):
         eng = FirEngine(fir, channels=channels, optimize_for=mode)
         y = torch.full_like(x, float("nan"))
+        torch.cuda.synchronize()   # the fill runs on torch's default stream: finished before another stream writes into the buffer
         for k in range(steps):                      # one launch per step
             eng.apply_device(x[k], y[k], 1, s)
         torch.cuda.synchronize()
         assert float((y - t).abs().max()) <= 1e-5 * scale, (mode, "per step")
         eng.reset()
         y2 = torch.full_like(x, float("nan"))
+        torch.cuda.synchronize()   # the fill runs on torch's default stream: finished before another stream writes into the buffer
         eng.apply_device(x[:4], y2[:4], 4, s)       # multi-step launches, split unevenly
         eng.apply_device(x[4:], y2[4:], steps - 4, s)
         torch.cuda.synchronize()
@@ -347,6 +352,7 @@ def test_live_session_config3_full_size_producer_on_a_second_stream(adsp):
     g = torch.Generator(device="cuda").manual_seed(41)
     x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=g)
     y = torch.full_like(x, float("nan"))
+    torch.cuda.synchronize()   # the fill runs on torch's default stream: finished before another stream writes into the buffer
     cons, prod = torch.cuda.Stream(), torch.cuda.Stream()
     torch.cuda.synchronize()
     copy = _copy_fn()
@@ -399,6 +405,7 @@ def test_live_session_host_publication_outputs_visible_while_it_runs(adsp, n, ki
     torch.cuda.synchronize()
     assert float((y0 - t[:2]).abs().max()) <= 1e-5 * scale
     out = torch.full((3, channels, n), float("nan"), device="cuda")
+    torch.cuda.synchronize()   # the fill runs on torch's default stream: finished before another stream writes into the buffer
     cons = torch.cuda.Stream()
     copy = _copy_fn()
     eng.live_start(out, 3, steps, None)
@@ -516,6 +523,7 @@ def test_library_pipelined_ring_steps_with_a_real_producer(adsp, n, kind, channe
     x = torch.empty((steps + 4, channels, n), device="cuda").uniform_(-1, 1, generator=g)
     t = _exact(adsp, fir, x)
     y = torch.full_like(x, float("nan"))
+    torch.cuda.synchronize()   # the fill runs on torch's default stream: finished before another stream writes into the buffer
     user = torch.cuda.Stream()
     copy = _copy_fn()
     eng.ring_set_pipeline(2)

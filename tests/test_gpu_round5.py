@@ -63,6 +63,7 @@ def test_upols_engine_matches_the_float64_direct_sum(adsp, n, taps_len, latency,
     g = torch.Generator(device="cuda").manual_seed(n)
     x = torch.empty((steps, channels, n), device="cuda").uniform_(-1, 1, generator=g)
     y = torch.full_like(x, 7.0)
+    torch.cuda.synchronize()   # the fill runs on torch's default stream: finished before another stream writes into the buffer
     s = torch.cuda.current_stream().cuda_stream
     pos = 0
     for k in calls:
@@ -324,6 +325,7 @@ def test_ring_steps_ride_a_live_session_with_a_real_producer(adsp, n, kind, chan
     eng.live_configure(step_timeout_ms=300.0)
     assert eng.ring_set_pipeline("auto") == 3
     y = torch.full_like(x, 7.0)
+    torch.cuda.synchronize()   # the fill runs on torch's default stream: finished before another stream writes into the buffer
     user = torch.cuda.Stream()
     sp = user.cuda_stream
     plane = channels * n * 4
@@ -380,7 +382,8 @@ def test_filter_change_in_a_stream_whose_steps_ride_a_session(adsp):
     ta, tb = _exact(adsp, fir_a, x), _exact(adsp, fir_b, x)
     eng = FirEngine(fir_a, channels=channels, ring_slots=8, optimize_for="stream")
     assert eng.ring_set_pipeline("auto") == 3
-    y = torch.zeros_like(x)
+    y = torch.empty_like(x)
+    torch.cuda.synchronize()   # (x, ta, tb were produced on torch's default stream; the session and `user` are streams of their own)
     user = torch.cuda.Stream()
     sp = user.cuda_stream
     for k in range(steps):
