@@ -224,6 +224,8 @@ __device__ __forceinline__ void upols_merge_pair(float& par, float& pai, float& 
 // launches spilled, and the 8192-point multiply launch needed 148 registers).  Instead thread 0 parks its registers in `park` (2 P floats of
 // LDS behind the exchange buffer), every lane runs the regular pairing - thread 0 on values it will not use - and thread 0 then pairs its
 // parked values its own way into the same registers.
+// (Two sequential ifs - `tid != 0`, then `tid == 0`, each rewriting in place, what fftconv_core.inc's spectrum_stage does - do not help here: 12 / 32 B of
+// scratch again on the 512-thread plan.  Thread 0's second pass must not READ registers.)
 template <class PL, class F0, class F1>
 __device__ __forceinline__ void upols_over_pairs(float (&xr)[PL::P], float (&xi)[PL::P], int tid, float2* park, F0 pair_fn, F1 bin0_fn) {
     constexpr int R = PL::RL, NB = PL::NBL;
