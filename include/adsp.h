@@ -577,6 +577,12 @@ ADSP_API int adsp_upols_bcast_spectra(adsp_upols* const* engines, int n, int roo
 ADSP_API int adsp_upols_bcast_spectra_rank(adsp_upols* fir, const char* unique_id, int rank, int world, int root);
 /* wait until everything this engine has launched - on `stream` or, if its last call went elsewhere, there - has finished */
 ADSP_API int adsp_upols_synchronize(adsp_upols* fir, void* stream);
+/* The block of the convolution axis that straddles the end of a call can be computed ONCE - its second part carried, as float32, to the head of
+ * the next call's output by that call's per-channel workgroups - or in both calls (rounds 5 - 6b).  Same samples either way; carrying saves one
+ * multiply + inverse transform per channel and call (one block in 6.4 at blocks of 16384 and Example4's chunk: -5 ... -7 % per call from 128
+ * channels on) and costs the short calls of few channels 1 - 2 % (one more copy on the call's critical path).  mode: -1 = the library decides
+ * per call (carry when the multiply launch has at least two workgroups per CU; the default), 0 = never, 1 = always (tests). */
+ADSP_API int adsp_upols_set_carry(adsp_upols* fir, int mode);
 /* Checkpoint / resume (the reference's whole state is its two previous chunks, EffectFFTFilter.py:40-42 - a partitioned
  * engine's is the transformed past): get_state drains the device and copies counters, input ring and frequency-domain delay line
  * into `state` (adsp_upols_state_bytes bytes: ~8 B per sample of delay line, 1.75 MiB per channel for Example4's low cut); set_state

@@ -128,6 +128,7 @@ SIGNATURES = {
     "adsp_upols_bcast_spectra": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]),
     "adsp_upols_bcast_spectra_rank": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "adsp_upols_synchronize": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "adsp_upols_set_carry": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "adsp_upols_state_bytes": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]),
     "adsp_upols_get_state": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "adsp_upols_set_state": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),

@@ -94,6 +94,7 @@ struct UpolsArgs {
     int P;               // partitions
     int R;               // delay-line slots per channel
     int slot_first;      // slot of the launch's first block
+    int p_first;         // (absolute index of the launch's first output block) mod P: where its partition order starts (multiply launch)
     int nblk;            // blocks in this launch
     int rel_first;       // forward: window start of the first block; mac: output time of the first block's first kept sample - relative to
                          // the first new input sample of the call (may be negative)
@@ -108,6 +109,12 @@ struct UpolsArgs {
     int cnt;             // chunks of this call that enter the ring: min(n_steps, nh)
     int epi_phase;       // fused tremolo (EffectTremolo.py:27-47): LFO table index of the call's first output sample ...
     int epi_replay;      // ... or, 1: every chunk replays the table from epi_phase (the reference's buffer quirk, adsp_capi.hip: tremolo_run)
+    // The block that straddles the end of the call is computed ONCE: what it holds beyond the call's last sample goes - as float32, before any
+    // effect - into carry_w[C][B], and the next call's per-channel workgroups copy it (effect, sample format) to the head of THEIR output
+    float2* carry_w;        // [C][B/2]: written by the launch's last block
+    const float2* carry_r;  // what the previous call left ...
+    int carry_stride;       // B
+    int carry_n;            // ... its first carry_n samples are this call's outputs 0 .. carry_n-1 (0: none - the launch starts with the straddling block)
 };
 
 namespace {
@@ -411,7 +418,52 @@ __device__ __forceinline__ void upols_keep_tail(const UpolsArgs& a) {
     const size_t plane = static_cast<size_t>(a.C) * N / 4, chan = static_cast<size_t>(c) * N / 4;
     const V* in = static_cast<const V*>(a.in);
     V* ring = static_cast<V*>(a.ring_w);
-    for (int u = static_cast<int>(threadIdx.x); u < a.tail / 4; u += static_cast<int>(blockDim.x)) {
+    const int nt = static_cast<int>(blockDim.x), t0 = static_cast<int>(threadIdx.x);
+    // (four requests in flight per lane: one workgroup moves up to 2 B + B samples of its channel, and at 64 channels a call is as long as its longest workgroup)
+    // what the previous call's straddling block computed for this call's first carry_n outputs: effect, sample format, the call's output array
+    if (a.carry_n > 0) {
+        using U = typename std::conditional<S16, unsigned, float>::type;
+        constexpr int SPU = S16 ? 2 : 1;
+        const float2* cr = a.carry_r + static_cast<size_t>(c) * (a.carry_stride / 2);
+        const size_t uplane = static_cast<size_t>(a.C) * N / SPU, uchan = static_cast<size_t>(c) * N / SPU;
+        const int len = static_cast<int>(a.epi_p2), n2 = a.carry_n / 2;
+        for (int i0 = t0; i0 < n2; i0 += 4 * nt) {
+            float2 vv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vv[j] = i0 + j * nt < n2 ? cr[i0 + j * nt] : make_float2(0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + j * nt;
+                if (i < n2) {
+                float2 v = vv[j];
+                const int tau = 2 * i;  // output times tau, tau + 1 of this call
+                int k, r;
+                locate_chunk(tau, N, a.inv_n, k, r);
+                if (a.epi_op == ADSP_EFFECT_TREMOLO) {  // (the multiply launch's indices: upols_mac_kernel)
+                    int n0, n1;
+                    if (a.epi_replay) {
+                        const int r1 = r + 1 == N ? 0 : r + 1;
+                        n0 = (a.epi_phase + r) % len;
+                        n1 = (a.epi_phase + r1) % len;
+                    } else {
+                        n0 = (a.epi_phase + tau) % len;
+                        n1 = n0 + 1 == len ? 0 : n0 + 1;
+                    }
+                    v.x *= tremolo_gain(n0, a.epi_p0, a.epi_p1);
+                    v.y *= tremolo_gain(n1, a.epi_p0, a.epi_p1);
+                } else if (a.epi_op != 0) {
+                    v.x = epilogue_value(v.x, a.epi_op, a.epi_p0, a.epi_p1, a.epi_p2);
+                    v.y = epilogue_value(v.y, a.epi_op, a.epi_p0, a.epi_p1, a.epi_p2);
+                }
+                U* dst = static_cast<U*>(a.out) + static_cast<size_t>(k) * uplane + uchan + r / SPU;
+                if constexpr (S16) *dst = pack_s16(v.x, v.y);
+                else *reinterpret_cast<float2*>(dst) = v;
+                }
+            }
+        }
+    }
+    // the input's tail into the ring
+    for (int u = t0; u < a.tail / 4; u += nt) {
         int k, r;
         locate_chunk(first + 4 * u, N, a.inv_n, k, r);
         int slot = a.ring_pos + 1 + (k - (a.n_steps - a.cnt));
@@ -500,7 +552,7 @@ __global__ __launch_bounds__(PL::T, PL::P > 32 ? 2 : (PL::T > 256 ? 4 : ADSP_UPO
         // fetch from HBM serves them all out of the L2.  (In the order 0 .. P-1 they read P different blocks per step and met each
         // again a step later, by when the XCD's other workgroups had pushed 4 - 8 MB through its 4 MB L2: the launch fetched
         // every block about twice, profiles/r5_upols_1024ch_counters.txt.)
-        int p = (a.slot_first + blk) % a.P;
+        int p = (a.p_first + blk) % a.P;  // = (absolute block index) mod P: the order of a block's sum - and so its rounding - does not depend on the call that computes it
         const float2* z = block_of(p);
         const float4* tab = a.pair + static_cast<size_t>(p) * a.pair_stride;
 #pragma unroll
@@ -531,6 +583,17 @@ __global__ __launch_bounds__(PL::T, PL::P > 32 ? 2 : (PL::T > 256 ? 4 : ADSP_UPO
     int ja, jb;
     upols_indices<PL>(tid, ja, jb);
     run_passes<PL, true, 0, const real4* __restrict__, (PL::P > 32 ? 1 : -1)>(ai, ar, lds, a.tw, tid, ja, jb);  // inverse = forward on swapped parts
+
+    if (a.carry_w && blk == a.nblk - 1) {  // workgroup-uniform: the launch's last block reaches beyond the call - those samples are the next call's first outputs
+        const int total_c = a.n_steps * a.N;
+        const int tau_c = a.rel_first + blk * PL::M - PL::M + 2 * tid;
+        float2* cw = a.carry_w + static_cast<size_t>(c) * (PL::M / 2);
+#pragma unroll
+        for (int m = P / 2; m < P; ++m) {
+            const int tau = tau_c + 2 * T * m;
+            if (tau >= total_c) cw[(tau - total_c) >> 1] = make_float2(ar[m], ai[m]);
+        }
+    }
 
     if (a.epi_op == ADSP_EFFECT_TREMOLO) {
         // the LFO's time base is the stream's own: register m of thread tid holds output times tau, tau + 1 with
@@ -667,6 +730,12 @@ struct adsp_upols {
     float4* tw;
     float4* pair;
     float2* zline;
+    float2* carry[2];  // [C][B/2] each: what the last block of a call computed beyond the call's end (upols_launch_pair), written alternately
+    int carry_w;       // the buffer the next launch writes
+    int carry_len;     // samples the previous call left for the head of the next one (multiple of 4, < B)
+    bool carry_valid;  // false: nothing usable (first call, reset, restored state, new filter) - the launch starts with the straddling block
+    int carry_mode;    // adsp_upols_set_carry: -1 the library decides per call, 0 never, 1 always
+    int cus;           // compute units of the device
     int pair_stride;
     int epi_op;
     float epi_p[3];
@@ -767,9 +836,24 @@ int upols_launch_pair(adsp_upols* u, const void* d_in, void* d_out, int n, hipSt
     const long long b_lo = floor_div(t_call - c.delay, kB), b_hi = floor_div(t_end - c.delay - 1, kB);
     if (b_hi > u->fwd_done) return fail(ADSP_ERR_STATE, "internal: output block %lld needs input that has not arrived", b_hi);
     if (u->fwd_done - (b_lo - c.n_partitions + 1) >= u->R) return fail(ADSP_ERR_STATE, "internal: the delay line is too short for this call");
-    a.nblk = (int)(b_hi - b_lo + 1);
-    a.slot_first = (int)(((b_lo % u->R) + u->R) % u->R);
-    a.rel_first = (int)(b_lo * kB + c.delay - t_call);  // output time of the block's first kept sample (circular index B)
+    // Block b_lo straddles the start of the call whenever t_call - delay is not a multiple of B: the PREVIOUS call computed it whole (its inputs had
+    // arrived: delay >= B), stored its own part and left the rest - this call's first carry_len outputs - in a carry buffer, which this launch's
+    // per-channel workgroups copy out (rounds 5 - 6b multiplied and inverse-transformed such a block in both calls: one block in 6.4 at B = 16384
+    // and Example4's chunk).  Not when nothing usable was left, or when the call ends inside that very block.
+    // ... and only where it pays: with fewer than two workgroups per CU a call is as long as its longest workgroup, and the per-channel workgroup's
+    // extra copy makes it 1 - 2 % longer (32 / 64 channels of Example4's chunk); from 128 channels on a call takes -2 ... -7 %
+    // (profiles/r6f_upols_carry_ab.txt).  A call that does not carry leaves nothing for the next one either.
+    const bool carry_on = u->carry_mode > 0 || (u->carry_mode < 0 && groups * (b_hi - b_lo + 1) >= 2LL * u->cus);
+    const bool use_carry = carry_on && u->carry_valid && u->carry_len > 0 && b_hi >= b_lo + 1;
+    const long long b_first = use_carry ? b_lo + 1 : b_lo;
+    a.nblk = (int)(b_hi - b_first + 1);
+    a.slot_first = (int)(((b_first % u->R) + u->R) % u->R);
+    a.rel_first = (int)(b_first * kB + c.delay - t_call);  // output time of the block's first kept sample (circular index B)
+    a.p_first = (int)(((b_first % c.n_partitions) + c.n_partitions) % c.n_partitions);
+    a.carry_w = carry_on ? u->carry[u->carry_w] : nullptr;
+    a.carry_r = u->carry[u->carry_w ^ 1];
+    a.carry_stride = (int)kB;
+    a.carry_n = use_carry ? u->carry_len : 0;
     const long long grid = groups * a.nblk;
     // ... plus one workgroup per channel that keeps the input's tail (the last min(2B, n N) samples) in the ring for the next call's windows
     const int cnt = n < u->nh ? n : u->nh;
@@ -781,6 +865,9 @@ int upols_launch_pair(adsp_upols* u, const void* d_in, void* d_out, int n, hipSt
     HIP_TRY(hipLaunchKernel(pl.mac[s16 ? 1 : 0], dim3((unsigned)(grid + c.n_channels)), dim3(pl.threads), kargs, pl.lds_bytes, stream));
     u->ring_pos = (u->ring_pos + cnt) % u->ring_slots;
     u->steps_done += n;
+    u->carry_len = (int)((b_hi + 1) * kB + c.delay - t_end);  // what block b_hi holds beyond this call: 0 .. B-4
+    u->carry_valid = carry_on;
+    u->carry_w ^= 1;
     return ADSP_OK;
 }
 }  // namespace
@@ -833,6 +920,7 @@ int upols_upload_tables(adsp_upols* u, const float* spectra) {
     }
     if (!u->pair) HIP_TRY(hipMalloc(&u->pair, all.size() * sizeof(float4)));
     HIP_TRY(hipMemcpy(u->pair, all.data(), all.size() * sizeof(float4), hipMemcpyHostToDevice));
+    u->carry_valid = false;  // (a carried block was multiplied by the filter before)
     if (!u->spectra) u->spectra = new std::vector<float>();
     u->spectra->assign(spectra, spectra + upols_spectra_floats(u));
     return ADSP_OK;
@@ -888,12 +976,15 @@ int adsp_upols_create(const adsp_upols_config* cfg, const float* spectra, adsp_u
     u->R = (int)(((long long)cfg->max_steps * N + cfg->delay + kB - 1) / kB) + cfg->n_partitions + 3;
     u->steps_done = 0;
     u->fwd_done = -1;
+    u->carry_mode = -1;
+    u->cus = 256;
     auto bail = [&](int code) {
         adsp_upols_destroy(u);
         return code;
     };
     hipError_t err;
     if ((err = hipSetDevice(cfg->device_id)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(err)));
+    if ((err = hipDeviceGetAttribute(&u->cus, hipDeviceAttributeMultiprocessorCount, cfg->device_id)) != hipSuccess || u->cus <= 0) u->cus = 256;
     if ((err = hipEventCreateWithFlags(&u->ev_done, hipEventDisableTiming)) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(err)));
     for (const void* fn : {plan->fwd[0], plan->fwd[1], plan->mac[0], plan->mac[1]})
         if ((err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, plan->lds_bytes)) != hipSuccess)
@@ -907,6 +998,9 @@ int adsp_upols_create(const adsp_upols_config* cfg, const float* spectra, adsp_u
         return bail(fail(ADSP_ERR_HIP, "hipMalloc delay line (%zu bytes = %d channels x %d blocks x %d bytes): %s", u->zline_bytes(), cfg->n_channels, u->R,
                          (int)(kB * sizeof(float2)), hipGetErrorString(err)));
     if ((err = hipMemset(u->zline, 0, u->zline_bytes())) != hipSuccess) return bail(fail(ADSP_ERR_HIP, "hipMemset: %s", hipGetErrorString(err)));
+    for (int i = 0; i < 2; ++i)
+        if ((err = hipMalloc(&u->carry[i], (size_t)cfg->n_channels * kB * sizeof(float))) != hipSuccess)
+            return bail(fail(ADSP_ERR_HIP, "hipMalloc carry buffer (%zu bytes): %s", (size_t)cfg->n_channels * kB * sizeof(float), hipGetErrorString(err)));
     // tables: the plan's twiddles, and per partition the pair tables of its spectrum - built exactly like an engine's
     const PlanInfo pl = plan->shape;
     std::vector<float4> tw;
@@ -926,7 +1020,7 @@ void adsp_upols_destroy(adsp_upols* u) {
     if (!u) return;
     (void)hipSetDevice(u->cfg.device_id);
     (void)hipDeviceSynchronize();
-    for (void* p : {(void*)u->ring, (void*)u->zeros, (void*)u->tw, (void*)u->pair, (void*)u->zline, (void*)u->stage_in, (void*)u->stage_out})
+    for (void* p : {(void*)u->ring, (void*)u->zeros, (void*)u->tw, (void*)u->pair, (void*)u->zline, (void*)u->carry[0], (void*)u->carry[1], (void*)u->stage_in, (void*)u->stage_out})
         if (p) (void)hipFree(p);
     if (u->ev_done) (void)hipEventDestroy(u->ev_done);
     if (u->d_spectra) (void)hipFree(u->d_spectra);
@@ -943,6 +1037,7 @@ int adsp_upols_reset(adsp_upols* u) {
     u->ring_pos = u->ring_slots - 1;
     u->steps_done = 0;
     u->fwd_done = -1;
+    u->carry_valid = false;
     u->lfo_copy_len = u->lfo_len;  // ... and the fused tremolo's LFO restarts (EffectTremolo.py:49-57)
     u->epi_phase = u->epi_replay = 0;
     return ADSP_OK;
@@ -993,6 +1088,13 @@ int adsp_upols_apply_device(adsp_upols* u, const void* d_in, void* d_out, int n_
     HIP_TRY(hipEventRecord(u->ev_done, st));
     u->last_stream = st;
     u->launched = true;
+    return ADSP_OK;
+}
+
+int adsp_upols_set_carry(adsp_upols* u, int mode) {
+    if (!u) return fail(ADSP_ERR_ARG, "NULL engine");
+    if (mode < -1 || mode > 1) return fail(ADSP_ERR_ARG, "mode %d: -1 (automatic), 0 (never) or 1 (always)", mode);
+    u->carry_mode = mode;  // (what a previous call carried stays usable: the same samples either way)
     return ADSP_OK;
 }
 
@@ -1073,6 +1175,7 @@ int adsp_upols_set_state(adsp_upols* u, const void* state, size_t bytes) {
     u->ring_pos = h.ring_pos;
     u->steps_done = h.steps_done;
     u->fwd_done = h.fwd_done;
+    u->carry_valid = false;  // (not part of a state: the first call after a resume computes its straddling block itself - same values)
     if (u->lfo_len > 0 && h.lfo_copy_len >= 1 && h.lfo_copy_len <= (long long)u->lfo_len + c.chunk_size) u->lfo_copy_len = h.lfo_copy_len;
     return ADSP_OK;
 }

@@ -614,6 +614,11 @@ class UpolsFirEngine:
         """Wait for everything the engine has launched (on `stream`, or wherever its last call went)."""
         _capi.check(self._lib.adsp_upols_synchronize(self._h, _ptr(stream)))
 
+    def set_carry(self, mode=-1):
+        """adsp_upols_set_carry: the block that straddles the end of a call computed once and carried to the next call's output (1), in
+        both calls (0), or as the library sees fit per call (-1, the default: carry from two workgroups per CU on).  Same samples."""
+        _capi.check(self._lib.adsp_upols_set_carry(self._h, int(mode)))
+
     def get_state(self):
         """The engine's whole state as one uint8 array (counters, input ring, frequency-domain delay line: adsp_upols_get_state);
         set_state on an engine of the same configuration continues the stream bit for bit."""

@@ -399,8 +399,9 @@ def test_filter_change_in_a_stream_whose_steps_ride_a_session(adsp):
     eng.close()
 
 
+@pytest.mark.parametrize("carry", [-1, 1])
 @pytest.mark.parametrize("seed", range(10))
-def test_upols_engine_randomised_shapes(adsp, seed):
+def test_upols_engine_randomised_shapes(adsp, seed, carry):
     """Seeded random long-kernel streams (chunk sizes that are multiples of 4, kernels of 1.1 - 3 chunks, any delay, 1 - 40 channels, calls
     of 1 - 3 chunks with sub-call splitting, float32 / int16): every sample against the float64 direct sum on the GPU."""
     import torch
@@ -415,6 +416,7 @@ def test_upols_engine_randomised_shapes(adsp, seed):
     taps = rng.standard_normal(taps_len) * np.hanning(taps_len) / np.sqrt(taps_len) * 2.0
     fir = adsp.FirStream(taps, n, latency_chunks=latency, lookahead=lookahead)
     eng = adsp.UpolsFirEngine(fir, channels=channels, sample_format=fmt, max_steps=int(rng.integers(1, 3)), block=8192 if seed % 2 or fir.delay - fir.delay % 4 < 16384 else 16384)
+    eng.set_carry(carry)   # (1: the block that straddles a call boundary is always carried over - with 1 - 40 channels the library would not)
     steps = sum(calls)
     g = torch.Generator(device="cuda").manual_seed(seed)
     if fmt == "s16":

@@ -203,23 +203,27 @@ def _long_fir(adsp, n=88200, taps_len=44099, seed=3, latency=1):
     return adsp.FirStream(taps, n, latency_chunks=latency, lookahead=taps_len // 2), taps
 
 
+@pytest.mark.parametrize("carry", [-1, 1])
 @pytest.mark.parametrize("block", [8192, 16384])
-def test_upols_state_roundtrip_reset_and_refusals(adsp, block):
+def test_upols_state_roundtrip_reset_and_refusals(adsp, block, carry):
     """Mirrors test_multistep_equals_streaming_and_state_roundtrip for the partitioned engine: a checkpoint taken mid-stream and
     restored into a FRESH engine continues the stream bit for bit; reset returns to the zero state; a state of another shape is refused."""
     fir, _ = _long_fir(adsp)
     n, channels, steps = fir.chunk_size, 3, 6
     x = seeded_stream(77, steps * channels * n).reshape(steps, channels, n)
     a = adsp.UpolsFirEngine(fir, channels=channels, block=block)
+    a.set_carry(carry)
     whole = np.concatenate([a.apply_host(x[k:k + 1]) for k in range(steps)])
     b = adsp.UpolsFirEngine(fir, channels=channels, block=block)
+    b.set_carry(carry)
     part1 = np.concatenate([b.apply_host(x[k:k + 1]) for k in range(3)])
     state = b.get_state()
     assert state.dtype == np.uint8 and state.size > b.delay_line_bytes
     part2 = np.concatenate([b.apply_host(x[k:k + 1]) for k in range(3, steps)])
     assert np.array_equal(np.concatenate([part1, part2]), whole)
     c = adsp.UpolsFirEngine(fir, channels=channels, block=block)
-    c.set_state(state)
+    c.set_carry(carry)
+    c.set_state(state)   # (what b carried over its third call's end is not part of the state: c computes that block itself - the same samples)
     assert np.array_equal(np.concatenate([c.apply_host(x[k:k + 1]) for k in range(3, steps)]), part2), "resume is bit for bit"
     c.reset()
     assert np.array_equal(np.concatenate([c.apply_host(x[k:k + 1]) for k in range(3)]), part1), "after reset"
@@ -238,6 +242,46 @@ def test_upols_state_roundtrip_reset_and_refusals(adsp, block):
         c.set_state(old_build)
     for e in (a, b, c, other):
         e.close()
+
+
+@pytest.mark.parametrize("fmt,effect", [("f32", None), ("f32", "tremolo"), ("f32", "saturator"), ("f32", "softclip"), ("s16", None)])
+@pytest.mark.parametrize("block", [8192, 16384])
+def test_upols_carry_equals_recompute(adsp, block, fmt, effect):
+    """adsp_upols_set_carry: the block that straddles the end of a call computed once and carried (float32, before the effect) to the next
+    call's output, against the same block computed in both calls: the SAME samples, bit for bit - float32 and int16, with a fused
+    stateless effect and with the tremolo (whose table index the carried samples take from the call they are delivered in), over calls of
+    1 - 3 chunks, a filter change (which drops what was carried) and a reset."""
+    n, channels = 20000, 5
+    fir, _ = _long_fir(adsp, n=n, taps_len=45001, seed=21, latency=3)
+    fir2, _ = _long_fir(adsp, n=n, taps_len=45001, seed=22, latency=3)
+    adsp.config.initialize(44100, n)
+    calls = [1, 2, 1, 3, 1, 1, 2]
+    total = sum(calls)
+    if fmt == "s16":
+        x = np.random.default_rng(5).integers(-9000, 9000, (total, channels, n)).astype(np.int16)
+    else:
+        x = seeded_stream(91, total * channels * n).reshape(total, channels, n)
+    fx = {None: None, "tremolo": lambda: adsp.CreateTremolo(0.7, 3.3), "saturator": lambda: adsp.CreateSaturator(),
+          "softclip": lambda: adsp.CreateSoftClipper()}[effect]
+    outs = []
+    for mode in (0, 1):
+        eng = adsp.UpolsFirEngine(fir, channels=channels, sample_format=fmt, max_steps=3, block=block)
+        eng.set_carry(mode)
+        if fx is not None:
+            eng.set_epilogue(fx())
+        got, k = [], 0
+        for i, m in enumerate(calls):
+            if i == 4:
+                eng.set_spectra(adsp.design.partition_uniform(fir2, block, eng.gain).spectra)   # the carried block belonged to the old filter
+            got.append(eng.apply_host(x[k:k + m]))
+            k += m
+        eng.reset()
+        got.append(eng.apply_host(x[:2]))
+        outs.append(np.concatenate(got))
+        eng.close()
+    adsp.config.initialize(44100, 4096)
+    assert outs[0].dtype == (np.int16 if fmt == "s16" else np.float32) and np.abs(outs[0].astype(np.float64)).max() > 0
+    assert np.array_equal(outs[0], outs[1]), f"{int((outs[0] != outs[1]).sum())} samples differ"
 
 
 def test_upols_calls_on_changing_streams_and_synchronize(adsp):

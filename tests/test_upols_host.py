@@ -25,6 +25,8 @@ class UpolsMirror:
         self.hist = np.zeros(self.nh * self.N)           # the ring: the last nh chunks
         self.zline = [(None, np.zeros(block + 1, complex)) for _ in range(self.R)]  # (block index held, spectrum)
         self.steps_done, self.fwd_done = 0, -1
+        self.carry, self.carry_valid = np.zeros(0), False  # what the last block of the previous call holds beyond that call's end
+        self.blocks_inverted = 0
 
     def _pair(self, x):
         N, B, n = self.N, self.B, len(x) // self.N
@@ -44,7 +46,11 @@ class UpolsMirror:
         assert b_hi <= self.fwd_done
         assert self.fwd_done - (b_lo - self.P + 1) < self.R
         out = np.full(n * N, np.nan)
-        for b in range(b_lo, b_hi + 1):
+        use_carry = self.carry_valid and len(self.carry) > 0 and b_hi >= b_lo + 1
+        if use_carry:                                    # the straddling block b_lo was computed whole by the previous call
+            out[:len(self.carry)] = self.carry
+        for b in range(b_lo + 1 if use_carry else b_lo, b_hi + 1):
+            self.blocks_inverted += 1
             acc = np.zeros(B + 1, complex)
             for p in range(self.P):
                 held, z = self.zline[(b - p) % self.R]
@@ -54,6 +60,9 @@ class UpolsMirror:
             tau0 = b * B + self.delay - t_call            # rel_first + blk * B
             lo, hi = max(0, tau0), min(n * N, tau0 + B)
             out[lo:hi] = y[lo - tau0:hi - tau0]
+            if b == b_hi:
+                self.carry, self.carry_valid = y[n * N - tau0:].copy(), True   # (b_hi + 1) B + delay - t_end samples
+                assert len(self.carry) == (b_hi + 1) * B + self.delay - t_end and 0 <= len(self.carry) < B
         assert not np.isnan(out).any(), "an output sample was produced by no block"
         cnt = min(n, self.nh)
         self.hist = np.concatenate([self.hist, x])[-self.nh * N:] if cnt else self.hist
