@@ -729,52 +729,68 @@ def numpy_api_latency(n=4096, reps=1500, warm=200, make="lowcut"):
     return (time.perf_counter() - t0) / reps * 1e6
 
 
-def long_kernel_figures(dev, channels=64, calls=24):
+def long_kernel_figures(dev, channels=64, calls=24, many_channels=1024):
     """Kernels longer than one transform in the reference's own shape (Example4.py:5, ModuleTestsGPU.py:35: chunk_size 88200 ->
     CreateLowCutFilter 44 099 taps, CreateEQ3BandFFT 88 197 taps): one call per chunk on device-resident float32 batches through
     make_engine (the uniformly partitioned engine, csrc/adsp_upols.hip), torch events over `calls` calls; checked against the float64
-    direct sum of adsp_exact on the last chunk of a fresh stream."""
+    direct sum of adsp_exact on the last chunk of a fresh stream.  `many_channels`: the same calls on that many channels (time only: the
+    call is bound by HBM there, by one workgroup's chain of work at 64)."""
     import torch
     import pyaudiodsptools_amd as adsp
     from pyaudiodsptools_amd import design, synth as asynth
     n, fs = 88200, 44100
     s = torch.cuda.current_stream(dev).cuda_stream
     out = {}
-    for name, taps in (("lowcut_44099_taps", design.lowcut_kernel(800, fs, n)), ("eq3_88197_taps", design.eq3_composite(100, 2, 700, -4, 8000, 5, fs, n))):
-        fir = adsp.FirStream(taps, n)
-        eng = adsp.make_engine(fir, channels=channels, device=dev.index)
-        x = torch.empty((4, channels, n), device=dev)
-        asynth.fill_device(x, 1234, 0, 0, channels, n, 4, "f32", 1.0, dev.index, s)
-        y = torch.empty((4, channels, n), device=dev)
-        eng.apply_device(x, y, 4, s)  # a fresh stream of four chunks: the parity sample
-        ex = adsp.ExactFirEngine(fir, channels=channels, device=dev.index)
-        t = torch.empty_like(y)
-        ex.apply_device(x, t, 4, s)
-        torch.cuda.synchronize(dev)
-        err = float((y[3] - t[3]).abs().max() / t[3].abs().max())
-        ex.close()
-        del t
+    kernels = (("lowcut_44099_taps", design.lowcut_kernel(800, fs, n)), ("eq3_88197_taps", design.eq3_composite(100, 2, 700, -4, 8000, 5, fs, n)))
+
+    def timed(fir, C, check):
+        eng = adsp.make_engine(fir, channels=C, device=dev.index)
+        x = torch.empty((4, C, n), device=dev)
+        asynth.fill_device(x, 1234, 0, 0, C, n, 4, "f32", 1.0, dev.index, s)
+        y = torch.empty((4 if check else 1, C, n), device=dev)
+        err = None
+        if check:
+            eng.apply_device(x, y, 4, s)  # a fresh stream of four chunks: the parity sample
+            ex = adsp.ExactFirEngine(fir, channels=C, device=dev.index)
+            t = torch.empty_like(y)
+            ex.apply_device(x, t, 4, s)
+            torch.cuda.synchronize(dev)
+            err = float((y[3] - t[3]).abs().max() / t[3].abs().max())
+            ex.close()
+            del t
+        ny = y.shape[0]
         t_pre = time.perf_counter()
         while time.perf_counter() - t_pre < 0.3:  # clock ramp: back-to-back calls (a synchronisation per call leaves the GPU idle half of the time)
             for k in range(8):
-                eng.apply_device(x[k % 4], y[k % 4], 1, s)
+                eng.apply_device(x[k % 4], y[k % ny], 1, s)
             torch.cuda.synchronize(dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         runs = []
         for _ in range(3):
             e0.record()
             for k in range(calls):
-                eng.apply_device(x[k % 4], y[k % 4], 1, s)
+                eng.apply_device(x[k % 4], y[k % ny], 1, s)
             e1.record()
             torch.cuda.synchronize(dev)
             runs.append(e0.elapsed_time(e1) * 1e-3 / calls)
         per = sorted(runs)[1]
-        out[name] = {"engine": type(eng).__name__, "block": getattr(eng, "block", None), "partitions": getattr(getattr(eng, "partition", None), "n_partitions", None),
-                     "us_per_call": round(per * 1e6, 1), "msamples_s": round(channels * n / per / 1e6, 1),
-                     "roofline_frac": round(ALG_BYTES_PER_SAMPLE * channels * n / per / (HBM_PEAK_GBS * 1e9), 4), "max_rel_err_vs_float64_direct_sum": float(f"{err:.3e}")}
+        res = {"engine": type(eng).__name__, "block": getattr(eng, "block", None), "partitions": getattr(getattr(eng, "partition", None), "n_partitions", None),
+               "us_per_call": round(per * 1e6, 1), "msamples_s": round(C * n / per / 1e6, 1),
+               "roofline_frac": round(ALG_BYTES_PER_SAMPLE * C * n / per / (HBM_PEAK_GBS * 1e9), 4)}
+        if err is not None:
+            res["max_rel_err_vs_float64_direct_sum"] = float(f"{err:.3e}")
         eng.close()
         del eng, x, y
         torch.cuda.empty_cache()
+        return res
+
+    for name, taps in kernels:
+        out[name] = timed(adsp.FirStream(taps, n), channels, True)
+    if many_channels:
+        try:
+            out[f"at_{many_channels}_channels"] = {name: timed(adsp.FirStream(taps, n), many_channels, False) for name, taps in kernels}
+        except Exception as exc:
+            out[f"at_{many_channels}_channels"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
     out["workload"] = f"{channels} channels x {n} samples per call (Example4.py:5), device-resident float32, median of 3 x {calls} calls"
     # ... and what Example4 itself does: ONE mono chunk of 88200 samples through the drop-in device, numpy in, numpy out
     try:
@@ -1199,7 +1215,7 @@ def main():
             except Exception as exc:
                 host_batches = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             try:
-                long_kernels = long_kernel_figures(dev)
+                long_kernels = long_kernel_figures(dev, many_channels=0 if getattr(args, "small", False) else 1024)
             except Exception as exc:
                 long_kernels = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             latency = {"config3_eq3_2048_stereo_pairs_x_512": c3,

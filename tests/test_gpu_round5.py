@@ -248,6 +248,10 @@ def test_bench_long_kernel_figures(adsp):
         assert r["engine"] == "UpolsFirEngine" and r["block"] == 8192 and r["partitions"] == parts
         assert r["us_per_call"] > 0 and r["msamples_s"] > 0 and 0 <= r["max_rel_err_vs_float64_direct_sum"] <= 1e-5
     assert "88200" in f["workload"] and all(v > 0 for v in f["numpy_api_1ch_us_per_call"].values())
+    many = f["at_1024_channels"]   # time only: blocks of 16384 there (design.choose_uniform_block)
+    for key, parts in (("lowcut_44099_taps", 3), ("eq3_88197_taps", 6)):
+        r = many[key]
+        assert r["engine"] == "UpolsFirEngine" and r["block"] == 16384 and r["partitions"] == parts and r["us_per_call"] > 0 and r["roofline_frac"] > 0.05
 
 
 def test_bench_exits_non_zero_without_a_line_when_the_world_is_not_what_was_asked_for():
