@@ -31,7 +31,8 @@
 // Time axis.  The stream is out[tau] = y[tau - delay], y = taps (*) s; blocks tile the y axis from absolute index 0, the chunk grid
 // is independent of them (chunk 88200 = 10.77 blocks).  A call for chunks k .. k+n-1 (input complete up to (k+n) N - 1) transforms
 // the blocks whose windows have just become complete and produces the output blocks that meet tau in [kN, (k+n)N); a block that
-// straddles a call boundary is multiplied and inverse-transformed in both calls (its forward transform once).  delay >= B keeps
+// straddles a call boundary is computed whole by the first of the two calls and its second part carried to the next call's output -
+// or, where that does not pay, multiplied and inverse-transformed in both (adsp_upols_set_carry; its forward transform once either way).  delay >= B keeps
 // every block an output needs inside the input that has arrived (the reference's devices delay by ~3/4 chunk).
 #include <hip/hip_runtime.h>
 
